@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the dino_predict hot path on N MI355X GPUs (BASELINE.json metric).
+
+A "step" is one pass of the hot path (patch-embed .. classifier head, C-ABI `dinov2_hip_predict`) over one batch of
+synthetic preprocessed 518x518 images that already sit in HBM; logits/probs stay on the device.  Workload at every N:
+BASELINE.json configs[2] = ViT-L/14 + 4 registers, f16, 518x518, batch 32 PER GPU (weak scaling: independent images,
+no data-path collective; the only collective is the one-time RCCL broadcast of rank 0's converted weight arena).
+
+  python bench.py                                   # N=1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W      # one rank per GPU over RCCL
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the FFN-in GEMM + GELU epilogue, 27 % of all
+FLOPs) from HIP events recorded around each of its launches on the session's own stream; `cpu_baseline` times the
+CPU oracle (restatement of the reference graph -- the reference itself cannot be built offline) on one image.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="large")
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=518)
+    ap.add_argument("--registers", type=int, default=4)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"])
+    ap.add_argument("--wtype", default="f16", help="GGUF storage type of the 2-D weights (f16, q8_0, q4_0, ...)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    args = ap.parse_args()
+
+    import torch  # plumbing only: device memory for the inputs, torch.distributed (RCCL) for N > 1
+    from __graft_entry__ import PKG_NAME, load_package
+    pkg = load_package()
+    from importlib import import_module
+    api = import_module(PKG_NAME + ".api")
+    D = import_module(PKG_NAME + ".dist")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    cfg = pkg.synth.CONFIGS[args.model]
+    num_classes = 1000
+    # ---- weights: rank 0 writes + loads + converts the synthetic GGUF; the others receive the arena over RCCL/xGMI
+    path = os.path.join(tempfile.gettempdir(), f"dinov2_{args.model}_r{args.registers}_{args.wtype}_seed42.gguf")
+    if rank == 0 and not os.path.exists(path):
+        tmp = path + f".{os.getpid()}.tmp"
+        pkg.synth.write_synthetic_gguf(tmp, args.model, registers=args.registers, num_classes=num_classes, seed=42,
+                                       wtype=args.wtype)
+        os.replace(tmp, path)
+    if dist is not None:
+        dist.barrier()
+    dt = api.F16 if args.dtype == "f16" else api.BF16
+    t_load = time.perf_counter()
+    model = api.Model(path, device=local, dtype=dt, classify=True, skip_tensor_data=(rank != 0))
+    bcast_ms = None
+    if dist is not None:
+        ptr, nbytes = model.arena()
+        arena = torch.as_tensor(D.DevPtr(ptr, nbytes), device=f"cuda:{local}")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        D.broadcast_weights(dist, arena, src=0)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - t0) * 1e3
+    load_s = time.perf_counter() - t_load
+    sess = api.Session(model)
+
+    B, S = args.batch, args.size
+    T = model.tokens(S, S)
+    gen = torch.Generator(device=f"cuda:{local}").manual_seed(42 + rank)
+    imgs = torch.randn((B, 3, S, S), generator=gen, device=f"cuda:{local}", dtype=torch.float32)
+    logits = torch.empty((B, num_classes), device=f"cuda:{local}", dtype=torch.float32)
+    probs = torch.empty_like(logits)
+
+    def step():
+        sess.predict_device(imgs.data_ptr(), B, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=logits.data_ptr(),
+                            probs_ptr=probs.data_ptr())
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        sess.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sess.sync()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        elapsed = D.max_over_ranks(dist, torch, elapsed, f"cuda:{local}")
+        dist.barrier()
+    if not bool(torch.isfinite(probs).all()):
+        raise SystemExit("non-finite probabilities")
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+    gflop_img = pkg.synth.flops_per_image(cfg, S, S, args.registers, num_classes) / 1e9
+
+    # ---- roofline of the dominant kernel: HIP events around every launch, on the stream the kernels run on ----
+    sess.profile(True)
+    prof_steps = 2
+    for _ in range(prof_steps):
+        step()
+    prof = sess.profile_read()
+    sess.profile(False)
+    H, F, L = cfg["hidden"], cfg["ffn"], cfg["layers"]
+    M = B * T
+    flops_launch = {  # algorithmic FLOPs per launch; padding does not count
+        "gemm_ffn_in": 2.0 * M * H * (2 * F if cfg["swiglu"] else F),
+        "gemm_ffn_out": 2.0 * M * F * H,
+        "gemm_qkv": 2.0 * M * H * 3 * H,
+        "gemm_attn_out": 2.0 * M * H * H,
+        "attention": 4.0 * B * T * T * H,
+        "gemm_patch_embed": 2.0 * B * (T - 1 - args.registers) * 588 * H,
+    }
+    kernels = {}
+    total_ms = sum(v[0] for v in prof.values()) or 1.0
+    for name, (ms, n) in prof.items():
+        if n == 0:
+            continue
+        avg = ms / n
+        k = {"avg_ms": round(avg, 4), "launches_per_step": n // prof_steps, "share": round(ms / total_ms, 4)}
+        if name in flops_launch:
+            k["tflops"] = round(flops_launch[name] / (avg * 1e-3) / 1e12, 1)
+        kernels[name] = k
+    dom = "gemm_ffn_in"
+    ach = kernels.get(dom, {}).get("tflops", 0.0)
+    roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "flops_per_launch": flops_launch[dom], "avg_launch_ms": kernels.get(dom, {}).get("avg_ms"),
+                "whole_forward_tflops": round(value / world * gflop_img / 1e3, 1),
+                "whole_forward_frac": round(value / world * gflop_img / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+
+    # ---- p50 latency at batch 1 (the other half of BASELINE.json's metric) ----
+    p50 = None
+    if not args.no_latency:
+        one = imgs[:1].contiguous()
+        lat = []
+        for i in range(25):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sess.predict_device(one.data_ptr(), 1, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=logits.data_ptr(),
+                                probs_ptr=probs.data_ptr())
+            sess.sync()
+            lat.append((time.perf_counter() - t0) * 1e3)
+        p50 = round(float(np.median(lat[5:])), 3)
+
+    # ---- CPU baseline: the oracle (restatement of the reference graph) on the host cores, bounded sample ----
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle.oracle import OracleModel
+        ora = OracleModel(path)
+        img1 = imgs[0].cpu().numpy()
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        exp = ora.forward(img1, classify=True)
+        cpu_s = time.perf_counter() - t0
+        got = logits[0].cpu().numpy() if B == 1 else None
+        # parity spot-check of the timed configuration itself (image 0 of the last step)
+        step()
+        sess.sync()
+        dl = float(np.abs(logits[0].cpu().numpy() - exp["logits"]).max())
+        cpu = {"value": round(1.0 / cpu_s, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+               "sample": f"1 image, {args.model} 518x518 batch 1, full predict, OpenMP {cores} threads",
+               "max_abs_logit_diff_vs_gpu": round(dl, 6)}
+        del got
+
+    out = {
+        "metric": "images/sec (518x518), ViT-L/14 fp16", "value": round(value, 2), "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"dinov2-{args.model} (ViT-{args.model[0].upper()}/14, {args.registers} registers) "
+                               f"{args.wtype} GGUF, {S}x{S}, batch={B} per GPU, classify head, random-init weights",
+                   "global_batch": world * B, "tokens_per_image": T, "parallelism": f"dp{world}",
+                   "gflop_per_image": round(gflop_img, 1)},
+        "p50_latency_ms_batch1": p50,
+        "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
+    }
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

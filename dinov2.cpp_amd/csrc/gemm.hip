@@ -1,0 +1,256 @@
+// gemm.hip -- f16/bf16 MFMA GEMM with fused epilogues for gfx950 (MI355X).
+//
+// Replaces every weight `ggml_mul_mat` + the elementwise nodes that follow it in the reference graph
+// (/root/reference/dinov2.cpp:471-474 qkv, :546-551 out-proj + :708-714 LayerScale/residual, :561-567 fc1+GELU,
+//  :570-573 fc2 + :744-749, :582-605 weights_in+SwiGLU, :608-611 weights_out, :636-671 patch-embed + pos-embed).
+// Numerics contract = ggml CPU mul_mat with F16 weights: activations rounded to the weight type, products and
+// accumulation in f32 (v_mfma_f32_32x32x16_{f16,bf16}).
+//
+// Structure (MI355X-first, not a CUDA tiling):
+//   * C[M,N] = A[M,K] * W[N,K]^T; both operands are K-contiguous, so A and B fragments are plain 16-byte
+//     ds_read_b128 of a row-major [rows][64 k] LDS image (128-byte rows).
+//   * 256x256x64 block tile, 8 wave64 (2 M x 4 N), each wave owns 128x64 = 4x2 MFMA 32x32 accumulators
+//     (128 acc VGPRs); 128x128x64 / 4 waves variant for small grids.
+//   * staging by global_load_lds_dwordx4 (HBM -> LDS without a VGPR round trip), double-buffered; the LDS image
+//     is lane-linear per wave instruction, so the bank swizzle is applied on the per-lane SOURCE address and
+//     again on the ds_read address: 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7), which makes every
+//     16-lane ds_read_b128 group hit 16 distinct bank slots.
+//   * 1-D grid with an XCD-aware remap so tiles that share an A row-panel run on the same XCD (shared L2).
+#include "device_types.h"
+#include "kernels.h"
+
+namespace dinov2 {
+
+template <typename T, int BM, int BN, int WM, int WN, int EPI>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+    using E = Elem<T>;
+    using vec8 = typename E::vec8;
+    constexpr int NW = WM * WN;
+    constexpr int BK = 64;
+    constexpr int ROWB = BK * 2;  // bytes per LDS row
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
+    constexpr int MREP = WTM / 32, NREP = WTN / 32;
+    constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // glds wave-instructions per wave per tile
+    static_assert(NREP == 2, "SwiGLU pairing and the register budget assume a 64-wide wave tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N, K = p.K;
+
+    const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    const int lid = xcd_remap(blockIdx.x, ntn * ntm);
+    const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+
+    // ---- per-lane staging sources (row clamped to the matrix: out-of-range rows re-read the last row) ----
+    const char* asrc[AI];
+    const char* bsrc[BI];
+    const int srow = lane >> 3;  // row within an 8-row wave-instruction
+#pragma unroll
+    for (int j = 0; j < AI; ++j) {
+        const int row = (j * NW + wid) * 8 + srow;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        int gm = m0 + row;
+        gm = gm < M ? gm : M - 1;
+        asrc[j] = (const char*)p.A + ((size_t)gm * K) * 2 + lc * 16;
+    }
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int row = (j * NW + wid) * 8 + srow;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        int gn = n0 + row;
+        gn = gn < N ? gn : N - 1;
+        bsrc[j] = (const char*)p.W + ((size_t)gn * K) * 2 + lc * 16;
+    }
+
+    auto stage = [&](int buf, int kt) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + BM * ROWB;
+        const size_t koff = (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < AI; ++j) glds16(asrc[j] + koff, sA + (j * NW + wid) * 8 * ROWB);
+#pragma unroll
+        for (int j = 0; j < BI; ++j) glds16(bsrc[j] + koff, sB + (j * NW + wid) * 8 * ROWB);
+    };
+
+    // ---- fragment read offsets ----
+    const int wm = wid / WN, wn = wid % WN;
+    const int fr = lane & 31;             // row within a 32-row MFMA block
+    const int fh = lane >> 5;             // which 8-wide k half of a 16-wide k step
+    const int sw = (fr >> 1) & 7;         // swizzle term (block bases are multiples of 32 rows)
+    const int aoff = (wm * WTM + fr) * ROWB;
+    const int boff = BM * ROWB + (wn * WTN + fr) * ROWB;
+
+    f32x16 acc[MREP][NREP];
+#pragma unroll
+    for (int i = 0; i < MREP; ++i)
+#pragma unroll
+        for (int j = 0; j < NREP; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        // one barrier per K tile: (a) every wave's loads of tile kt have landed (vmcnt(0) precedes the barrier),
+        // (b) every wave is done reading the buffer tile kt+1 is about to overwrite
+        __syncthreads();
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* s = smem + (kt & 1) * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ch = ((ks * 2 + fh) ^ sw) << 4;
+            vec8 af[MREP], bf[NREP];
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) af[i] = *(const vec8*)(s + aoff + i * 32 * ROWB + ch);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) bf[j] = *(const vec8*)(s + boff + j * 32 * ROWB + ch);
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+        }
+    }
+
+    // ---- epilogue: acc[i][j][r] is C[row, col] with
+    //      row = m0 + wm*WTM + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),  col = n0 + wn*WTN + j*32 + (lane&31)
+    const int colb = n0 + wn * WTN + fr;
+    const int rowb = m0 + wm * WTM + 4 * fh;
+
+    if constexpr (EPI == EPI_SWIGLU) {
+        // W rows interleaved in 32-blocks: n-block 2q holds x1[32q..], n-block 2q+1 holds x2[32q..]
+        const int c1 = colb, c2 = colb + 32;
+        const float b1 = (p.bias && c1 < N) ? p.bias[c1] : 0.f;
+        const float b2 = (p.bias && c2 < N) ? p.bias[c2] : 0.f;
+        const int j = ((n0 + wn * WTN) >> 6) * 32 + fr;  // hidden unit index
+        T* out = (T*)p.out;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < M && c2 < N) {
+                    const float h1 = acc[i][0][r] + b1, h2 = acc[i][1][r] + b2;
+                    const float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1));  // silu, dinov2.cpp:605
+                    out[(size_t)row * p.ldo + j] = E::from_f32(sl * h2);
+                }
+            }
+        return;
+    } else {
+#pragma unroll
+        for (int jn = 0; jn < NREP; ++jn) {
+            const int col = colb + jn * 32;
+            if (col >= N) continue;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+            float auxv = 0.f;
+            if constexpr (EPI == EPI_RESID) auxv = p.aux[col];
+            if constexpr (EPI == EPI_QKV) auxv = col < p.qcols ? p.qscale : 1.0f;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                float xin[16];
+                if constexpr (EPI == EPI_RESID) {
+                    // issue all 16 residual loads (rows clamped, unconditional) before the first dependent store
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
+                        row = row < M ? row : M - 1;
+                        xin[r] = ((const float*)p.out)[(size_t)row * p.ldo + col];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row >= M) continue;
+                    const float v = acc[i][jn][r] + bias;
+                    if constexpr (EPI == EPI_PATCH) {
+                        const int b = row / p.P, pp = row - b * p.P;
+                        float* x = (float*)p.out;
+                        x[((size_t)b * p.T + 1 + p.R + pp) * p.ldo + col] = v + p.aux[(size_t)(1 + pp) * N + col];
+                    } else if constexpr (EPI == EPI_QKV) {
+                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(v * auxv);
+                    } else if constexpr (EPI == EPI_RESID) {
+                        ((float*)p.out)[(size_t)row * p.ldo + col] = v * auxv + xin[r];
+                    } else if constexpr (EPI == EPI_GELU) {
+                        // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))), x<=-10 -> 0, x>=10 -> x
+                        const float xr = (float)(_Float16)v;
+                        const float u = 0.79788456080286535587989211986876f * xr * (1.0f + 0.044715f * xr * xr);
+                        float g = xr * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));  // == 0.5 x (1 + tanh u)
+                        g = (float)(_Float16)g;
+                        g = v <= -10.0f ? 0.0f : (v >= 10.0f ? v : g);
+                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(g);
+                    } else {  // EPI_PLAIN_F32
+                        ((float*)p.out)[(size_t)row * p.ldo + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
+    const dim3 grid(ntn * ntm), block(WM * WN * 64);
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+#define DINO_LAUNCH(E)                                                                             \
+    case E:                                                                                        \
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, E>), grid, block, lds, st, a);         \
+        break;
+    switch (epi) {
+        DINO_LAUNCH(EPI_PATCH)
+        DINO_LAUNCH(EPI_QKV)
+        DINO_LAUNCH(EPI_RESID)
+        DINO_LAUNCH(EPI_GELU)
+        DINO_LAUNCH(EPI_SWIGLU)
+        DINO_LAUNCH(EPI_PLAIN_F32)
+    }
+#undef DINO_LAUNCH
+    return hipGetLastError();
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+static hipError_t set_attr_cfg() {
+    const int lds = 2 * (BM + BN) * 128;
+    hipError_t e = hipSuccess;
+#define DINO_ATTR(E)                                                                                          \
+    if (e == hipSuccess)                                                                                      \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, E>),            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DINO_ATTR(EPI_PATCH)
+    DINO_ATTR(EPI_QKV)
+    DINO_ATTR(EPI_RESID)
+    DINO_ATTR(EPI_GELU)
+    DINO_ATTR(EPI_SWIGLU)
+    DINO_ATTR(EPI_PLAIN_F32)
+#undef DINO_ATTR
+    return e;
+}
+
+hipError_t gemm_init() {
+    hipError_t e = set_attr_cfg<_Float16, 256, 256, 2, 4>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 256, 256, 2, 4>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 128, 128, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 128, 128, 2, 2>();
+    return e;
+}
+
+// Tile choice: 256x256 needs N % 256 == 0 (QKV blocks must not straddle q|k|v, SwiGLU pairs must not straddle a
+// tile) and enough tiles to fill 256 CUs; otherwise 128x128 (N % 128 == 0 for the same reasons, else edge-guarded).
+static bool use_big_tile(const GemmArgs& a) {
+    if (a.N % 256 != 0) return false;
+    const long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
+    return tiles >= 192;
+}
+
+hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    const bool big = use_big_tile(a);
+    if (dt == DT_F16)
+        return big ? launch_cfg<_Float16, 256, 256, 2, 4>(epi, a, st) : launch_cfg<_Float16, 128, 128, 2, 2>(epi, a, st);
+    return big ? launch_cfg<__bf16, 256, 256, 2, 4>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2>(epi, a, st);
+}
+
+}  // namespace dinov2

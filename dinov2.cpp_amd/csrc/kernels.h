@@ -1,0 +1,75 @@
+// Launcher interface of the hand-written gfx950 kernels (gemm.hip, attention.hip, kernels_misc.hip).
+// All launchers enqueue on `stream` and return hipGetLastError(); none of them allocates or syncs.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dinov2 {
+
+enum DType : int { DT_F16 = 0, DT_BF16 = 1 };
+
+// GEMM epilogues.  C[m,n] = sum_k A[m,k] * W[n,k] (f32 accumulate), then:
+enum Epilogue : int {
+    EPI_PATCH = 0,   // x[b*T + 1+R+p, n] = acc + bias[n] + pos[1+p, n]           (f32 out; m = b*P + p)
+    EPI_QKV = 1,     // out[m, n] = T((acc + bias[n]) * (n < qcols ? qscale : 1))  (T out)
+    EPI_RESID = 2,   // x[m, n] += ls[n] * (acc + bias[n])                         (f32 in/out)
+    EPI_GELU = 3,    // out[m, n] = T(f16(gelu_tanh(f16(acc + bias[n]))))          (T out; ggml f16-LUT contract)
+    EPI_SWIGLU = 4,  // out[m, j] = T(silu(h1) * h2), rows of W interleaved in 32-blocks x1|x2 (T out, width N/2)
+    EPI_PLAIN_F32 = 5  // out[m, n] = acc + bias[n]                                (f32 out; tests / head)
+};
+
+struct GemmArgs {
+    const void* A;      // [M, K]  T, row-major, K % 64 == 0
+    const void* W;      // [N, K]  T, row-major (ggml ne = [K, N])
+    const float* bias;  // [N] or nullptr
+    void* out;
+    const float* aux;   // EPI_PATCH: pos [1+P, N]; EPI_RESID: layer-scale lambda [N]
+    int M, N, K;
+    int ldo;            // leading dimension of out in elements
+    int P, T, R;        // EPI_PATCH token mapping
+    int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale
+    float qscale;
+};
+
+hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);
+// must be called once per device before the first launch_gemm (raises the dynamic-LDS limit)
+hipError_t gemm_init();
+
+// y[r, :] = T(((x - mean) * rsqrt(var + eps)) * w + b)     x f32 [rows, H]; one wave per row
+hipError_t launch_layernorm(DType dt, const float* x, const float* w, const float* b, void* y, int rows, int H,
+                            float eps, hipStream_t stream);
+// same, f32 output (final layernorm)
+hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int H, float eps,
+                                hipStream_t stream);
+
+// fused multi-head attention over token-major qkv [B*T, 3H] (T dtype, q pre-scaled), out [B*T, H]; hd == 64
+hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, hipStream_t stream);
+
+// im2col of conv_2d_sk_p0: img f32 (layout 0 = BGR HWC interleaved, 1 = RGB CHW planar) -> col [B*P, Kpad] T,
+// patch vector order (c_rgb, ky, kx), zero padded to Kpad
+hipError_t launch_im2col(DType dt, const float* img, void* col, int B, int Hh, int Ww, int patch, int Kpad, int layout,
+                         hipStream_t stream);
+// x[b*T + 0] = cls + pos[0]; x[b*T + 1 + r] = reg[r]
+hipError_t launch_init_tokens(float* x, const float* cls, const float* pos, const float* reg, int B, int T, int R,
+                              int H, hipStream_t stream);
+
+// load-time conversion of one GGUF tensor: src (ggml type) rows [N, K] -> dst T [N, Kpad], zero padded.
+// interleave32 > 0: destination row order x1|x2 interleaved in 32-row blocks (SwiGLU weights_in), value = F.
+hipError_t launch_convert_weight(DType dt, const void* src, uint32_t ggml_type, void* dst, int N, int K, int Kpad,
+                                 int interleaveF, hipStream_t stream);
+// f32 vector copy with the same optional interleave (bias of weights_in)
+hipError_t launch_permute_bias(const float* src, float* dst, int N, int interleaveF, hipStream_t stream);
+
+// classifier head (forward_head): fin = final-LN tokens f32 [B, T, H]
+//   pooled[b, h] = sum_{t in [first, T)} fin[b, t, h] * inv_div ; feat = [cls ; pooled] rounded to T
+//   logits = W feat + bias ; probs = softmax(logits)
+hipError_t launch_head(DType dt, const float* fin, const void* W, const float* bias, float* feat_scratch,
+                       float* logits, float* probs, int B, int T, int H, int C, int first, float inv_div,
+                       hipStream_t stream);
+
+// debugging aid: what ds_read_b64_tr_b16 returns per lane for addr = lane*8 over an LDS image holding its own
+// element index (out: [64][4] int16)
+hipError_t launch_probe_tr16(int16_t* out, hipStream_t stream);
+
+}  // namespace dinov2

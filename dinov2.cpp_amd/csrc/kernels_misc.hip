@@ -1,0 +1,329 @@
+// kernels_misc.hip -- the HBM-bound kernels around the GEMMs: LayerNorm, im2col, token init, load-time weight
+// conversion / dequantisation, classifier head.  All are wavefront (64-lane) designs with 16-byte accesses.
+#include "device_types.h"
+#include "gguf_reader.h"
+#include "kernels.h"
+
+namespace dinov2 {
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm: ggml_norm + mul + add  (/root/reference/dinov2.cpp:694-700, 722-728, 756-760)
+// one wave per token row, row kept in registers (H <= 1536 -> <= 6 float4 per lane), statistics in double like
+// ggml (mean, then centred sum of squares), 1/sqrtf(var + eps) in f32.
+// ---------------------------------------------------------------------------------------------------------
+template <typename OutT, int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bta, OutT* __restrict__ y, int rows,
+                                                        int H, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = H >> 2;
+    const float4* xr = (const float4*)(x + (size_t)row * H);
+    float4 v[MAXV];
+    double sum = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+            v[j] = xr[i];
+            sum += (double)v[j].x + (double)v[j].y + (double)v[j].z + (double)v[j].w;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = (float)(sum / H);
+    double sq = 0.0;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+            v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
+            sq += (double)(v[j].x * v[j].x) + (double)(v[j].y * v[j].y) + (double)(v[j].z * v[j].z) +
+                  (double)(v[j].w * v[j].w);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float var = (float)(sq / H);
+    const float scale = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+            const float4 ww = ((const float4*)w)[i], bb = ((const float4*)bta)[i];
+            const float r0 = v[j].x * scale * ww.x + bb.x, r1 = v[j].y * scale * ww.y + bb.y;
+            const float r2 = v[j].z * scale * ww.z + bb.z, r3 = v[j].w * scale * ww.w + bb.w;
+            if constexpr (sizeof(OutT) == 4) {
+                ((float4*)(y + (size_t)row * H))[i] = make_float4(r0, r1, r2, r3);
+            } else {
+                typedef OutT o4 __attribute__((ext_vector_type(4)));
+                o4 pk;
+                pk[0] = (OutT)r0; pk[1] = (OutT)r1; pk[2] = (OutT)r2; pk[3] = (OutT)r3;
+                ((o4*)(y + (size_t)row * H))[i] = pk;
+            }
+        }
+    }
+}
+
+template <typename OutT>
+static hipError_t ln_dispatch(const float* x, const float* w, const float* b, OutT* y, int rows, int H, float eps,
+                              hipStream_t st) {
+    if (H % 4 != 0 || H > 64 * 4 * 8) return hipErrorInvalidValue;
+    const dim3 grid((rows + 3) / 4), block(256);
+    const int nv = (H / 4 + 63) / 64;
+    if (nv <= 2) hipLaunchKernelGGL((layernorm_kernel<OutT, 2>), grid, block, 0, st, x, w, b, y, rows, H, eps);
+    else if (nv <= 4) hipLaunchKernelGGL((layernorm_kernel<OutT, 4>), grid, block, 0, st, x, w, b, y, rows, H, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<OutT, 8>), grid, block, 0, st, x, w, b, y, rows, H, eps);
+    return hipGetLastError();
+}
+
+hipError_t launch_layernorm(DType dt, const float* x, const float* w, const float* b, void* y, int rows, int H, float eps,
+                            hipStream_t st) {
+    return dt == DT_F16 ? ln_dispatch<_Float16>(x, w, b, (_Float16*)y, rows, H, eps, st)
+                        : ln_dispatch<__bf16>(x, w, b, (__bf16*)y, rows, H, eps, st);
+}
+
+hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int H, float eps,
+                                hipStream_t st) {
+    return ln_dispatch<float>(x, w, b, y, rows, H, eps, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// im2col of ggml_conv_2d_sk_p0 (/root/reference/dinov2.cpp:636): image -> [B*P, Kpad] in the kernel's type,
+// patch vector order (c, ky, kx) with kx fastest == flattening the [H,3,14,14] weight row; c is the RGB index
+// (dino_predict repacks BGR-interleaved to RGB-planar first, dinov2.cpp:914-931 -- folded into the gather here).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int Hh,
+                                                     int Ww, int ps, int Kpad, int layout) {
+    const int w0 = Ww / ps, h0 = Hh / ps, P = w0 * h0;
+    const int cpr = Kpad >> 3;  // 8-element chunks per row
+    const size_t total = (size_t)B * P * cpr;
+    const int Kreal = 3 * ps * ps, pp2 = ps * ps;
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(idx % cpr);
+        const size_t rowi = idx / cpr;
+        const int p = (int)(rowi % P), b = (int)(rowi / P);
+        const int py = p / w0, px = p - py * w0;
+        t8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            float v = 0.f;
+            if (k < Kreal) {
+                const int c = k / pp2, rem = k - c * pp2;
+                const int ky = rem / ps, kx = rem - ky * ps;
+                const int yy = py * ps + ky, xx = px * ps + kx;
+                v = layout == 1 ? img[(((size_t)b * 3 + c) * Hh + yy) * Ww + xx]
+                                : img[(((size_t)b * Hh + yy) * Ww + xx) * 3 + (2 - c)];
+            }
+            o[e] = (T)v;
+        }
+        *(t8*)(col + rowi * Kpad + ch * 8) = o;
+    }
+}
+
+hipError_t launch_im2col(DType dt, const float* img, void* col, int B, int Hh, int Ww, int patch, int Kpad, int layout,
+                         hipStream_t st) {
+    const size_t total = (size_t)B * (Hh / patch) * (Ww / patch) * (Kpad / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dt == DT_F16)
+        hipLaunchKernelGGL(im2col_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, img, (_Float16*)col, B, Hh, Ww, patch,
+                           Kpad, layout);
+    else
+        hipLaunchKernelGGL(im2col_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, img, (__bf16*)col, B, Hh, Ww, patch, Kpad,
+                           layout);
+    return hipGetLastError();
+}
+
+// x[b, 0] = cls + pos[0];  x[b, 1 + r] = register_tokens[r]  (no pos-embed on registers)  dinov2.cpp:662-685
+__global__ void init_tokens_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                   const float* __restrict__ reg, int T, int R, int H) {
+    const int b = blockIdx.y, t = blockIdx.x;  // t in [0, 1+R)
+    float* dst = x + ((size_t)b * T + t) * H;
+    for (int i = threadIdx.x; i < H; i += blockDim.x) dst[i] = t == 0 ? cls[i] + pos[i] : reg[(size_t)(t - 1) * H + i];
+}
+
+hipError_t launch_init_tokens(float* x, const float* cls, const float* pos, const float* reg, int B, int T, int R, int H,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(init_tokens_kernel, dim3(1 + R, B), dim3(256), 0, st, x, cls, pos, reg, T, R, H);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// load-time weight conversion: one GGUF 2-D tensor [N rows, K] of any supported ggml type -> T [N, Kpad].
+// Quant block layouts (32 weights per block, d/m are f16): Q4_0 {d, qs[16]}, Q4_1 {d, m, qs[16]},
+// Q5_0 {d, qh[4], qs[16]}, Q5_1 {d, m, qh[4], qs[16]}, Q8_0 {d, int8 qs[32]}  (ggml-quants dequantize_row_*;
+// the reference leaves dequantisation to ggml's vec_dot, /root/reference/dinov2.cpp:227-236, 355-453).
+// ---------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float ld_f16(const uint8_t* p) {
+    const uint16_t u = (uint16_t)p[0] | ((uint16_t)p[1] << 8);
+    return (float)__builtin_bit_cast(_Float16, u);
+}
+
+static __device__ __forceinline__ float dequant_elem(const uint8_t* src, uint32_t type, size_t row, int K, int k) {
+    switch (type) {
+        case GGML_F32: return ((const float*)src)[row * K + k];
+        case GGML_F16: return (float)((const _Float16*)src)[row * K + k];
+        case GGML_BF16: return (float)((const __bf16*)src)[row * K + k];
+        default: break;
+    }
+    const size_t blk = row * (size_t)(K >> 5) + (k >> 5);
+    const int j = k & 31;
+    switch (type) {
+        case GGML_Q8_0: {
+            const uint8_t* b = src + blk * 34;
+            return (float)(int8_t)b[2 + j] * ld_f16(b);
+        }
+        case GGML_Q4_0: {
+            const uint8_t* b = src + blk * 18;
+            const int q = j < 16 ? (b[2 + j] & 0xF) : (b[2 + j - 16] >> 4);
+            return (float)(q - 8) * ld_f16(b);
+        }
+        case GGML_Q4_1: {
+            const uint8_t* b = src + blk * 20;
+            const int q = j < 16 ? (b[4 + j] & 0xF) : (b[4 + j - 16] >> 4);
+            return (float)q * ld_f16(b) + ld_f16(b + 2);
+        }
+        case GGML_Q5_0: {
+            const uint8_t* b = src + blk * 22;
+            const uint32_t qh = (uint32_t)b[2] | ((uint32_t)b[3] << 8) | ((uint32_t)b[4] << 16) | ((uint32_t)b[5] << 24);
+            const int lo = j < 16 ? (b[6 + j] & 0xF) : (b[6 + j - 16] >> 4);
+            const int q = lo | (int)(((qh >> j) & 1u) << 4);
+            return (float)(q - 16) * ld_f16(b);
+        }
+        case GGML_Q5_1: {
+            const uint8_t* b = src + blk * 24;
+            const uint32_t qh = (uint32_t)b[4] | ((uint32_t)b[5] << 8) | ((uint32_t)b[6] << 16) | ((uint32_t)b[7] << 24);
+            const int lo = j < 16 ? (b[8 + j] & 0xF) : (b[8 + j - 16] >> 4);
+            const int q = lo | (int)(((qh >> j) & 1u) << 4);
+            return (float)q * ld_f16(b) + ld_f16(b + 2);
+        }
+        default: return 0.f;
+    }
+}
+
+static __device__ __forceinline__ int interleave_src_row(int n, int F) {
+    // destination rows alternate 32-row blocks x1[32q..] | x2[32q..]; source is [x1 (F rows); x2 (F rows)]
+    const int blk = n >> 5, within = n & 31;
+    return (blk & 1) * F + (blk >> 1) * 32 + within;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_weight_kernel(const uint8_t* __restrict__ src, uint32_t type,
+                                                             T* __restrict__ dst, int N, int K, int Kpad, int F) {
+    const size_t total = (size_t)N * Kpad;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % Kpad);
+        const int n = (int)(idx / Kpad);
+        const int sr = F > 0 ? interleave_src_row(n, F) : n;
+        dst[idx] = k < K ? (T)dequant_elem(src, type, (size_t)sr, K, k) : (T)0.f;
+    }
+}
+
+hipError_t launch_convert_weight(DType dt, const void* src, uint32_t type, void* dst, int N, int K, int Kpad, int F,
+                                 hipStream_t st) {
+    const size_t total = (size_t)N * Kpad;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (dt == DT_F16)
+        hipLaunchKernelGGL(convert_weight_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)src, type,
+                           (_Float16*)dst, N, K, Kpad, F);
+    else
+        hipLaunchKernelGGL(convert_weight_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const uint8_t*)src, type,
+                           (__bf16*)dst, N, K, Kpad, F);
+    return hipGetLastError();
+}
+
+__global__ void permute_bias_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int F) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N) dst[n] = src[F > 0 ? interleave_src_row(n, F) : n];
+}
+
+hipError_t launch_permute_bias(const float* src, float* dst, int N, int F, hipStream_t st) {
+    hipLaunchKernelGGL(permute_bias_kernel, dim3((N + 255) / 256), dim3(256), 0, st, src, dst, N, F);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// classifier head = forward_head (/root/reference/dinov2.cpp:792-821)
+// ---------------------------------------------------------------------------------------------------------
+// feat[b] = [cls ; sum_t fin[b, t, :] * inv_div] rounded to the weight type (ggml mul_mat activation rounding);
+// sum_rows accumulates in double like ggml_vec_sum_f32.
+template <typename T>
+__global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ fin, float* __restrict__ feat, int T_,
+                                                        int H, int first, float inv_div) {
+    const int b = blockIdx.y;
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H) return;
+    const float* f = fin + (size_t)b * T_ * H;
+    double s = 0.0;
+    for (int t = first; t < T_; ++t) s += (double)f[(size_t)t * H + h];
+    feat[(size_t)b * 2 * H + h] = (float)(T)f[h];
+    feat[(size_t)b * 2 * H + H + h] = (float)(T)((float)s * inv_div);
+}
+
+// one wave per class: logits[b, c] = bias[c] + sum_k W[c, k] * feat[b, k]
+template <typename T>
+__global__ __launch_bounds__(256) void head_logits_kernel(const float* __restrict__ feat, const T* __restrict__ W,
+                                                          const float* __restrict__ bias, float* __restrict__ logits,
+                                                          int K, int C) {
+    const int b = blockIdx.y;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const T* wr = W + (size_t)c * K;
+    const float* fr = feat + (size_t)b * K;
+    float acc = 0.f;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        const t8 wv = *(const t8*)(wr + k);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += (float)wv[e] * fr[k + e];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) logits[(size_t)b * C + c] = acc + bias[c];
+}
+
+// ggml_soft_max: max, expf(x - max), sum in double, scale by (float)(1/sum)
+__global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                                           int C) {
+    __shared__ float smax[4];
+    __shared__ double ssum[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* l = logits + (size_t)b * C;
+    float mx = -INFINITY;
+    for (int c = threadIdx.x; c < C; c += 256) mx = fmaxf(mx, l[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) smax[w] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    double s = 0.0;
+    for (int c = threadIdx.x; c < C; c += 256) s += (double)expf(l[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) ssum[w] = s;
+    __syncthreads();
+    const float inv = (float)(1.0 / (ssum[0] + ssum[1] + ssum[2] + ssum[3]));
+    for (int c = threadIdx.x; c < C; c += 256) probs[(size_t)b * C + c] = expf(l[c] - mx) * inv;
+}
+
+hipError_t launch_head(DType dt, const float* fin, const void* W, const float* bias, float* feat, float* logits,
+                       float* probs, int B, int T_, int H, int C, int first, float inv_div, hipStream_t st) {
+    const dim3 pg((H + 255) / 256, B), lg((C + 3) / 4, B);
+    if (dt == DT_F16) {
+        hipLaunchKernelGGL(head_pool_kernel<_Float16>, pg, dim3(256), 0, st, fin, feat, T_, H, first, inv_div);
+        hipLaunchKernelGGL(head_logits_kernel<_Float16>, lg, dim3(256), 0, st, feat, (const _Float16*)W, bias, logits,
+                           2 * H, C);
+    } else {
+        hipLaunchKernelGGL(head_pool_kernel<__bf16>, pg, dim3(256), 0, st, fin, feat, T_, H, first, inv_div);
+        hipLaunchKernelGGL(head_logits_kernel<__bf16>, lg, dim3(256), 0, st, feat, (const __bf16*)W, bias, logits, 2 * H, C);
+    }
+    hipLaunchKernelGGL(head_softmax_kernel, dim3(B), dim3(256), 0, st, logits, probs, C);
+    return hipGetLastError();
+}
+
+}  // namespace dinov2

@@ -1,0 +1,821 @@
+// model.cpp -- loader, session, forward orchestration and the C-ABI of libdinov2_hip.so.
+//
+// Replaces, from the reference (lavaman131/dinov2.cpp):
+//   dino_model_load        /root/reference/dinov2.cpp:239-352   -> dinov2_hip_model_load
+//   interpolate_pos_embed  /root/reference/dinov2.cpp:159-225   -> interpolate_pos_embed() below (no OpenCV)
+//   build_graph + dino_predict  :823-838, :900-999              -> forward() + dinov2_hip_predict
+// There is no graph builder / allocator / backend scheduler here: the forward is a fixed sequence of ~8 fused
+// kernel launches per layer on one HIP stream over a pre-carved workspace.
+#include "model.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <numeric>
+
+#include "gguf_reader.h"
+
+using namespace dinov2;
+
+namespace {
+
+enum Kind : int {
+    K_IM2COL = 0, K_INIT, K_PATCH_GEMM, K_LAYERNORM, K_QKV_GEMM, K_ATTENTION, K_OPROJ_GEMM, K_FC1_GEMM, K_FC2_GEMM,
+    K_FINAL_LN, K_HEAD, K_COUNT
+};
+const char* const kKindNames[K_COUNT] = {"im2col", "init_tokens", "gemm_patch_embed", "layernorm", "gemm_qkv",
+                                         "attention", "gemm_attn_out", "gemm_ffn_in", "gemm_ffn_out", "final_layernorm",
+                                         "head"};
+
+void set_err(char* err, size_t n, const char* fmt, ...) {
+    if (!err || n == 0) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err, n, fmt, ap);
+    va_end(ap);
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            set_err(err, errlen, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return DINOV2_HIP_ERR_HIP;                                                             \
+        }                                                                                          \
+    } while (0)
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- cv::resize(INTER_CUBIC) for CV_32F, restated without OpenCV: separable cubic convolution, A = -0.75,
+// source coordinate (d + 0.5) * (src/dst) - 0.5, four taps floor-1..floor+2 clamped to the border, no antialias.
+void cubic_taps(float t, float w[4]) {
+    const float A = -0.75f;
+    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+
+struct Axis {
+    std::vector<int> idx;    // 4 per destination coordinate
+    std::vector<float> wgt;  // 4 per destination coordinate
+};
+
+Axis make_axis(int src, int dst) {
+    Axis a;
+    a.idx.resize(4 * (size_t)dst);
+    a.wgt.resize(4 * (size_t)dst);
+    const float scale = (float)src / (float)dst;
+    for (int d = 0; d < dst; ++d) {
+        float f = ((float)d + 0.5f) * scale - 0.5f;
+        const int s = (int)std::floor(f);
+        f -= (float)s;
+        cubic_taps(f, &a.wgt[4 * (size_t)d]);
+        for (int k = 0; k < 4; ++k) a.idx[4 * (size_t)d + k] = std::min(std::max(s - 1 + k, 0), src - 1);
+    }
+    return a;
+}
+
+// interpolate_pos_embed (dinov2.cpp:159-225).  pos: [1 + M*M, H]; out: [1 + h*w, H].  Identity when the patch
+// COUNT matches (the reference compares counts, not shapes: dinov2.cpp:176-179).
+void interpolate_pos_embed(const float* pos, int M, int H, int h_new, int w_new, float* out) {
+    std::memcpy(out, pos, sizeof(float) * (size_t)H);
+    if (h_new * w_new == M * M) {
+        std::memcpy(out + H, pos + H, sizeof(float) * (size_t)M * M * H);
+        return;
+    }
+    const Axis ax = make_axis(M, w_new), ay = make_axis(M, h_new);
+    std::vector<float> rowbuf((size_t)4 * H);
+    for (int dy = 0; dy < h_new; ++dy) {
+        const int* iy = &ay.idx[4 * (size_t)dy];
+        const float* wy = &ay.wgt[4 * (size_t)dy];
+        for (int dx = 0; dx < w_new; ++dx) {
+            const int* ix = &ax.idx[4 * (size_t)dx];
+            const float* wx = &ax.wgt[4 * (size_t)dx];
+            float* o = out + (size_t)(1 + dy * w_new + dx) * H;
+            for (int ky = 0; ky < 4; ++ky) {  // horizontal pass per source row, then vertical blend
+                float* rb = &rowbuf[(size_t)ky * H];
+                const float* r0 = pos + (size_t)(1 + iy[ky] * M + ix[0]) * H;
+                const float* r1 = pos + (size_t)(1 + iy[ky] * M + ix[1]) * H;
+                const float* r2 = pos + (size_t)(1 + iy[ky] * M + ix[2]) * H;
+                const float* r3 = pos + (size_t)(1 + iy[ky] * M + ix[3]) * H;
+                for (int c = 0; c < H; ++c) rb[c] = r0[c] * wx[0] + r1[c] * wx[1] + r2[c] * wx[2] + r3[c] * wx[3];
+            }
+            for (int c = 0; c < H; ++c)
+                o[c] = rowbuf[c] * wy[0] + rowbuf[(size_t)H + c] * wy[1] + rowbuf[(size_t)2 * H + c] * wy[2] +
+                       rowbuf[(size_t)3 * H + c] * wy[3];
+        }
+    }
+}
+
+// ---- arena planning --------------------------------------------------------------------------------------
+struct Plan {
+    struct Item {
+        std::string name;   // GGUF tensor name
+        void** slot;        // where the device pointer goes
+        bool matrix;        // 2-D weight converted to the compute dtype, else f32 vector copied as is
+        int N, K, Kpad;     // matrix dims (rows, cols, padded cols)
+        int interleaveF;    // SwiGLU weights_in row interleave (0 = off)
+        size_t offset, bytes;
+    };
+    std::vector<Item> items;
+    size_t total = 0;
+    void add(const std::string& name, void** slot, bool matrix, int N, int K, int Kpad, int F, size_t bytes) {
+        Item it{name, slot, matrix, N, K, Kpad, F, total, bytes};
+        total += align_up(bytes, 256);
+        items.push_back(it);
+    }
+};
+
+struct Dims {
+    int P, T, M;
+};
+
+}  // namespace
+
+// =============================================================================================================
+// load
+// =============================================================================================================
+extern "C" void dinov2_hip_default_load_opts(dinov2_hip_load_opts* o) {
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->device = 0;
+    o->compute_dtype = DINOV2_HIP_F16;
+    o->classify = 1;
+    o->skip_tensor_data = 0;
+    o->quirk_pool_const_divisor = 1;
+    o->quirk_pool_includes_registers = 1;
+}
+
+extern "C" int dinov2_hip_abi_version(void) { return DINOV2_HIP_ABI_VERSION; }
+
+extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opts* opts_in, dinov2_hip_model** out,
+                                     char* err, size_t errlen) {
+    if (!path || !out) {
+        set_err(err, errlen, "null argument");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    dinov2_hip_load_opts opts;
+    if (opts_in) opts = *opts_in; else dinov2_hip_default_load_opts(&opts);
+    if (opts.compute_dtype != DINOV2_HIP_F16 && opts.compute_dtype != DINOV2_HIP_BF16) {
+        set_err(err, errlen, "compute_dtype must be F16 or BF16");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+
+    GgufFile gg;
+    std::string msg;
+    if (!gg.open(path, &msg)) {
+        set_err(err, errlen, "%s", msg.c_str());
+        const bool io = msg.rfind("failed to open", 0) == 0 || msg.rfind("mmap", 0) == 0;
+        return io ? DINOV2_HIP_ERR_IO : DINOV2_HIP_ERR_FORMAT;
+    }
+
+    std::unique_ptr<dinov2_hip_model> m(new dinov2_hip_model());
+    auto& hp = m->hp;
+    // hparams: u32 KVs, every one required (the reference asserts on a missing key, dinov2.cpp:58)
+    struct { const char* key; uint32_t* dst; bool required; } keys[] = {
+        {"hidden_size", &hp.hidden_size, true},           {"num_hidden_layers", &hp.num_hidden_layers, true},
+        {"num_attention_heads", &hp.num_attention_heads, true}, {"patch_size", &hp.patch_size, true},
+        {"img_size", &hp.img_size, true},                 {"ftype", &hp.ftype, true},
+        {"num_register_tokens", &hp.num_register_tokens, false}, {"num_classes", &hp.num_classes, false}};
+    for (auto& k : keys) {
+        *k.dst = 0;
+        if (!gg.get_u32(k.key, k.dst) && k.required) {
+            set_err(err, errlen, "GGUF key '%s' is missing", k.key);
+            return DINOV2_HIP_ERR_FORMAT;
+        }
+    }
+    hp.eps = 1e-6f;
+    hp.compute_dtype = (uint32_t)opts.compute_dtype;
+    m->dt = opts.compute_dtype == DINOV2_HIP_BF16 ? DT_BF16 : DT_F16;
+    m->device = opts.device;
+    m->quirk_const_div = opts.quirk_pool_const_divisor != 0;
+    m->quirk_pool_regs = opts.quirk_pool_includes_registers != 0;
+
+    const int H = (int)hp.hidden_size, L = (int)hp.num_hidden_layers, nh = (int)hp.num_attention_heads;
+    const int ps = (int)hp.patch_size, R = (int)hp.num_register_tokens;
+    if (H <= 0 || L <= 0 || nh <= 0 || ps <= 0 || hp.img_size < hp.patch_size) {
+        set_err(err, errlen, "invalid hparams in '%s'", path);
+        return DINOV2_HIP_ERR_FORMAT;
+    }
+    if (H != nh * 64) {
+        set_err(err, errlen, "unsupported head dim %d (the DINOv2 family and this build use 64)", H / std::max(nh, 1));
+        return DINOV2_HIP_ERR_UNSUPPORTED;
+    }
+    if (H % 64 != 0) {
+        set_err(err, errlen, "hidden_size %d is not a multiple of 64", H);
+        return DINOV2_HIP_ERR_UNSUPPORTED;
+    }
+    const int Mgrid = (int)(hp.img_size / hp.patch_size);
+
+    auto need = [&](const std::string& name, const GgufTensor** t) -> bool {
+        *t = gg.tensor(name);
+        if (!*t) set_err(err, errlen, "GGUF tensor '%s' is missing", name.c_str());
+        return *t != nullptr;
+    };
+
+    // FFN flavour: by tensor presence (equivalent to the reference's `num_hidden_layers == 40`, dinov2.cpp:740)
+    const bool swiglu = gg.tensor("encoder.layer.0.mlp.weights_in.weight") != nullptr;
+    hp.swiglu = swiglu;
+    const GgufTensor* t = nullptr;
+    if (!need(swiglu ? "encoder.layer.0.mlp.weights_out.weight" : "encoder.layer.0.mlp.fc1.weight", &t))
+        return DINOV2_HIP_ERR_FORMAT;
+    if (t->ne.size() < 2) {
+        set_err(err, errlen, "tensor '%s' is not 2-D", t->name.c_str());
+        return DINOV2_HIP_ERR_FORMAT;
+    }
+    const int F = swiglu ? (int)t->ne[0] : (int)t->ne[1];
+    hp.ffn_hidden = (uint32_t)F;
+    if (F % 64 != 0) {
+        set_err(err, errlen, "FFN hidden size %d is not a multiple of 64", F);
+        return DINOV2_HIP_ERR_UNSUPPORTED;
+    }
+    if (!need("encoder.layer.0.attention.attention.qkv.weight", &t)) return DINOV2_HIP_ERR_FORMAT;
+    hp.weight_type = t->type;
+
+    const GgufTensor* head = gg.tensor("classifier.weight");
+    const bool want_head = opts.classify != 0 && head != nullptr;
+    hp.has_classifier = want_head;
+    int C = 0;
+    if (want_head) {
+        C = (int)(head->ne.size() >= 2 ? head->ne[1] : 0);
+        if (C <= 0 || (int)head->ne[0] != 2 * H) {
+            set_err(err, errlen, "classifier.weight has unexpected shape");
+            return DINOV2_HIP_ERR_FORMAT;
+        }
+        hp.num_classes = (uint32_t)C;
+        m->labels.resize((size_t)C);
+        for (int i = 0; i < C; ++i) {  // id2label string KVs "0".."C-1" (dinov2.cpp:301-305)
+            const GgufValue* v = gg.find(std::to_string(i));
+            m->labels[(size_t)i] = v ? v->s : std::string();
+        }
+    }
+
+    // ---- plan the arena ----
+    const size_t esz = 2;
+    m->kpe = 3 * ps * ps;
+    m->kpe_pad = (int)align_up((size_t)m->kpe, 64);
+    m->layers.resize((size_t)L);
+    Plan plan;
+    auto vec = [&](const std::string& n, float** slot, int count, int F_il = 0) {
+        plan.add(n, (void**)slot, false, count, 1, 1, F_il, sizeof(float) * (size_t)count);
+    };
+    auto mat = [&](const std::string& n, void** slot, int N, int K, int Kpad, int F_il = 0) {
+        plan.add(n, slot, true, N, K, Kpad, F_il, esz * (size_t)N * Kpad);
+    };
+    vec("embeddings.cls_token", &m->cls, H);
+    vec("embeddings.position_embeddings", &m->pos, (1 + Mgrid * Mgrid) * H);
+    if (R > 0) vec("embeddings.register_tokens", &m->reg, R * H);
+    mat("embeddings.patch_embeddings.projection.weight", &m->patch_w, H, m->kpe, m->kpe_pad);
+    vec("embeddings.patch_embeddings.projection.bias", &m->patch_b, H);
+    for (int i = 0; i < L; ++i) {
+        const std::string b = "encoder.layer." + std::to_string(i) + ".";
+        LayerWeights& ly = m->layers[(size_t)i];
+        vec(b + "norm1.weight", &ly.norm1_w, H);
+        vec(b + "norm1.bias", &ly.norm1_b, H);
+        mat(b + "attention.attention.qkv.weight", &ly.qkv_w, 3 * H, H, H);
+        vec(b + "attention.attention.qkv.bias", &ly.qkv_b, 3 * H);
+        mat(b + "attention.output.dense.weight", &ly.o_w, H, H, H);
+        vec(b + "attention.output.dense.bias", &ly.o_b, H);
+        vec(b + "layer_scale1.lambda1", &ly.ls1, H);
+        vec(b + "norm2.weight", &ly.norm2_w, H);
+        vec(b + "norm2.bias", &ly.norm2_b, H);
+        if (swiglu) {
+            mat(b + "mlp.weights_in.weight", &ly.fc1_w, 2 * F, H, H, F);
+            vec(b + "mlp.weights_in.bias", &ly.fc1_b, 2 * F, F);
+            mat(b + "mlp.weights_out.weight", &ly.fc2_w, H, F, F);
+            vec(b + "mlp.weights_out.bias", &ly.fc2_b, H);
+        } else {
+            mat(b + "mlp.fc1.weight", &ly.fc1_w, F, H, H);
+            vec(b + "mlp.fc1.bias", &ly.fc1_b, F);
+            mat(b + "mlp.fc2.weight", &ly.fc2_w, H, F, F);
+            vec(b + "mlp.fc2.bias", &ly.fc2_b, H);
+        }
+        vec(b + "layer_scale2.lambda1", &ly.ls2, H);
+    }
+    vec("layernorm.weight", &m->ln_w, H);
+    vec("layernorm.bias", &m->ln_b, H);
+    if (want_head) {
+        mat("classifier.weight", &m->head_w, C, 2 * H, 2 * H);
+        vec("classifier.bias", &m->head_b, C);
+    }
+
+    // validate every tensor against the plan before touching the device
+    size_t max_raw = 0;
+    for (auto& it : plan.items) {
+        const GgufTensor* gt = nullptr;
+        if (!need(it.name, &gt)) return DINOV2_HIP_ERR_FORMAT;
+        const uint64_t want = it.matrix ? (uint64_t)it.N * it.K : (uint64_t)it.N;
+        if (gt->nelements() != want) {
+            set_err(err, errlen, "tensor '%s' has %llu elements, expected %llu", it.name.c_str(),
+                    (unsigned long long)gt->nelements(), (unsigned long long)want);
+            return DINOV2_HIP_ERR_FORMAT;
+        }
+        if (it.matrix && (int)gt->ne[0] != it.K && it.name.find("patch_embeddings") == std::string::npos) {
+            set_err(err, errlen, "tensor '%s' has row length %llu, expected %d", it.name.c_str(),
+                    (unsigned long long)gt->ne[0], it.K);
+            return DINOV2_HIP_ERR_FORMAT;
+        }
+        if (!it.matrix && gt->type != GGML_F32) {
+            set_err(err, errlen, "tensor '%s' must be F32 (the converter writes 1-D / embedding tensors as F32)",
+                    it.name.c_str());
+            return DINOV2_HIP_ERR_UNSUPPORTED;
+        }
+        if (it.matrix && it.name.find("patch_embeddings") != std::string::npos && gt->type != GGML_F16 &&
+            gt->type != GGML_F32 && gt->type != GGML_BF16) {
+            set_err(err, errlen, "patch-embedding kernel must be F16/F32/BF16");
+            return DINOV2_HIP_ERR_UNSUPPORTED;
+        }
+        max_raw = std::max(max_raw, (size_t)gt->nbytes);
+    }
+
+    // ---- device side ----
+    HIP_TRY(hipSetDevice(opts.device));
+    HIP_TRY(gemm_init());
+    m->arena_bytes = plan.total;
+    HIP_TRY(hipMalloc((void**)&m->arena, plan.total));
+    for (auto& it : plan.items) *it.slot = m->arena + it.offset;
+
+    // host copy of the position embeddings for per-resolution interpolation
+    {
+        const GgufTensor* pt = gg.tensor("embeddings.position_embeddings");
+        m->pos_host.assign((const float*)pt->data, (const float*)pt->data + pt->nelements());
+    }
+
+    if (!opts.skip_tensor_data) {
+        char* staging = nullptr;
+        HIP_TRY(hipMalloc((void**)&staging, align_up(max_raw, 256)));
+        int rc = DINOV2_HIP_OK;
+        for (auto& it : plan.items) {
+            const GgufTensor* gt = gg.tensor(it.name);
+            hipError_t e = hipSuccess;
+            if (!it.matrix && it.interleaveF == 0) {
+                e = hipMemcpy(*it.slot, gt->data, gt->nbytes, hipMemcpyHostToDevice);
+            } else {
+                e = hipMemcpy(staging, gt->data, gt->nbytes, hipMemcpyHostToDevice);
+                if (e == hipSuccess) {
+                    if (it.matrix)
+                        e = launch_convert_weight(m->dt, staging, gt->type, *it.slot, it.N, it.K, it.Kpad, it.interleaveF,
+                                                  nullptr);
+                    else
+                        e = launch_permute_bias((const float*)staging, (float*)*it.slot, it.N, it.interleaveF, nullptr);
+                }
+                if (e == hipSuccess) e = hipDeviceSynchronize();  // staging is reused by the next tensor
+            }
+            if (e != hipSuccess) {
+                set_err(err, errlen, "uploading '%s' failed: %s", it.name.c_str(), hipGetErrorString(e));
+                rc = DINOV2_HIP_ERR_HIP;
+                break;
+            }
+        }
+        (void)hipFree(staging);
+        if (rc != DINOV2_HIP_OK) {
+            (void)hipFree(m->arena);
+            return rc;
+        }
+    }
+    *out = m.release();
+    return DINOV2_HIP_OK;
+}
+
+extern "C" void dinov2_hip_model_free(dinov2_hip_model* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->arena) (void)hipFree(m->arena);
+    delete m;
+}
+
+extern "C" int dinov2_hip_model_hparams(const dinov2_hip_model* m, dinov2_hip_hparams* out) {
+    if (!m || !out) return DINOV2_HIP_ERR_INVALID;
+    *out = m->hp;
+    return DINOV2_HIP_OK;
+}
+
+extern "C" const char* dinov2_hip_model_label(const dinov2_hip_model* m, int32_t id) {
+    if (!m || id < 0 || (size_t)id >= m->labels.size()) return nullptr;
+    return m->labels[(size_t)id].c_str();
+}
+
+extern "C" int dinov2_hip_model_arena(dinov2_hip_model* m, void** ptr, size_t* bytes) {
+    if (!m || !ptr || !bytes) return DINOV2_HIP_ERR_INVALID;
+    *ptr = m->arena;
+    *bytes = m->arena_bytes;
+    return DINOV2_HIP_OK;
+}
+
+extern "C" int dinov2_hip_interpolate_pos_embed(const dinov2_hip_model* m, int32_t h_new, int32_t w_new, float* out) {
+    if (!m || !out || h_new <= 0 || w_new <= 0) return DINOV2_HIP_ERR_INVALID;
+    interpolate_pos_embed(m->pos_host.data(), (int)(m->hp.img_size / m->hp.patch_size), (int)m->hp.hidden_size, h_new,
+                          w_new, out);
+    return DINOV2_HIP_OK;
+}
+
+// =============================================================================================================
+// session
+// =============================================================================================================
+namespace {
+
+Dims dims_of(const dinov2_hip_model* m, int B, int h, int w) {
+    Dims d;
+    d.P = (h / (int)m->hp.patch_size) * (w / (int)m->hp.patch_size);
+    d.T = 1 + (int)m->hp.num_register_tokens + d.P;
+    d.M = B * d.T;
+    return d;
+}
+
+struct Carve {
+    size_t img, col, x, ln, qkv, att, hid, fin, feat, logits, probs, pos, total;
+};
+
+Carve carve_of(const dinov2_hip_model* m, int B, int h, int w) {
+    const Dims d = dims_of(m, B, h, w);
+    const size_t H = m->hp.hidden_size, F = m->hp.ffn_hidden, C = std::max<size_t>(m->hp.num_classes, 1);
+    Carve c{};
+    size_t off = 0;
+    auto put = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    c.img = put(sizeof(float) * 3 * (size_t)B * h * w);
+    c.col = put(2 * (size_t)B * d.P * m->kpe_pad);
+    c.x = put(sizeof(float) * (size_t)d.M * H);
+    c.ln = put(2 * (size_t)d.M * H);
+    c.qkv = put(2 * (size_t)d.M * 3 * H);
+    c.att = put(2 * (size_t)d.M * H);
+    c.hid = put(2 * (size_t)d.M * F);
+    c.fin = put(sizeof(float) * (size_t)d.M * H);
+    c.feat = put(sizeof(float) * (size_t)B * 2 * H);
+    c.logits = put(sizeof(float) * (size_t)B * C);
+    c.probs = put(sizeof(float) * (size_t)B * C);
+    c.pos = put(sizeof(float) * (size_t)(1 + d.P) * H);
+    c.total = off;
+    return c;
+}
+
+int ensure_workspace(dinov2_hip_session* s, int B, int h, int w, char* err, size_t errlen) {
+    if (s->cur_b == B && s->cur_h == h && s->cur_w == w && s->ws) return DINOV2_HIP_OK;
+    const Carve c = carve_of(s->model, B, h, w);
+    if (c.total > s->ws_bytes) {
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        if (s->ws) HIP_TRY(hipFree(s->ws));
+        s->ws = nullptr;
+        s->ws_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&s->ws, c.total));
+        s->ws_bytes = c.total;
+    }
+    s->img = (float*)(s->ws + c.img);
+    s->col = s->ws + c.col;
+    s->x = (float*)(s->ws + c.x);
+    s->ln = s->ws + c.ln;
+    s->qkv = s->ws + c.qkv;
+    s->att = s->ws + c.att;
+    s->hid = s->ws + c.hid;
+    s->fin = (float*)(s->ws + c.fin);
+    s->feat = (float*)(s->ws + c.feat);
+    s->logits = (float*)(s->ws + c.logits);
+    s->probs = (float*)(s->ws + c.probs);
+    s->pos = (float*)(s->ws + c.pos);
+    s->pos_h = s->pos_w = -1;  // the carve moved: re-upload the pos-embed
+    s->cur_b = B;
+    s->cur_h = h;
+    s->cur_w = w;
+    return DINOV2_HIP_OK;
+}
+
+struct Scope {  // optional per-launch event pair
+    dinov2_hip_session* s;
+    int kind;
+    hipEvent_t a = nullptr, b = nullptr;
+    Scope(dinov2_hip_session* s_, int kind_) : s(s_), kind(kind_) {
+        if (!s->profiling) return;
+        auto get = [&]() {
+            hipEvent_t e = nullptr;
+            if (!s->free_events.empty()) {
+                e = s->free_events.back();
+                s->free_events.pop_back();
+            } else {
+                (void)hipEventCreate(&e);
+            }
+            return e;
+        };
+        a = get();
+        b = get();
+        (void)hipEventRecord(a, s->stream);
+    }
+    ~Scope() {
+        if (!s->profiling) return;
+        (void)hipEventRecord(b, s->stream);
+        s->records.push_back(ProfRecord{kind, a, b});
+    }
+};
+
+void drain_profile(dinov2_hip_session* s) {
+    if (s->prof_ms.empty()) {
+        s->prof_ms.assign(K_COUNT, 0.0);
+        s->prof_n.assign(K_COUNT, 0);
+    }
+    for (auto& r : s->records) {
+        (void)hipEventSynchronize(r.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            s->prof_ms[(size_t)r.kind] += ms;
+            s->prof_n[(size_t)r.kind] += 1;
+        }
+        s->free_events.push_back(r.a);
+        s->free_events.push_back(r.b);
+    }
+    s->records.clear();
+}
+
+// The forward pass: forward_features (dinov2.cpp:616-790) [+ forward_head :792-821], `nlayers` <= L layers.
+// `img` is a DEVICE pointer.  Leaves final-LN tokens in s->fin, logits/probs in s->logits/s->probs.
+int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int layout, bool classify, int nlayers,
+            bool finalize, char* err, size_t errlen) {
+    const dinov2_hip_model* m = s->model;
+    const int H = (int)m->hp.hidden_size, F = (int)m->hp.ffn_hidden, R = (int)m->hp.num_register_tokens;
+    const int nh = (int)m->hp.num_attention_heads, ps = (int)m->hp.patch_size;
+    const Dims d = dims_of(m, B, h, w);
+    const int h0 = h / ps, w0 = w / ps;
+    hipStream_t st = s->stream;
+    const DType dt = m->dt;
+
+    // pos-embed for this grid, cached per (h0, w0): the reference recomputes it on every call (dinov2.cpp:937)
+    if (s->pos_h != h0 || s->pos_w != w0) {
+        HIP_TRY(hipStreamSynchronize(st));  // pos_stage may still be in flight from a previous shape
+        s->pos_stage.resize((size_t)(1 + d.P) * H);
+        interpolate_pos_embed(m->pos_host.data(), (int)(m->hp.img_size / m->hp.patch_size), H, h0, w0,
+                              s->pos_stage.data());
+        HIP_TRY(hipMemcpyAsync(s->pos, s->pos_stage.data(), sizeof(float) * s->pos_stage.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        s->pos_h = h0;
+        s->pos_w = w0;
+    }
+
+    {
+        Scope sc(s, K_IM2COL);
+        HIP_TRY(launch_im2col(dt, img, s->col, B, h, w, ps, m->kpe_pad, layout, st));
+    }
+    {
+        Scope sc(s, K_INIT);
+        HIP_TRY(launch_init_tokens(s->x, m->cls, s->pos, m->reg, B, d.T, R, H, st));
+    }
+    {
+        Scope sc(s, K_PATCH_GEMM);
+        GemmArgs a{};
+        a.A = s->col; a.W = m->patch_w; a.bias = m->patch_b; a.out = s->x; a.aux = s->pos;
+        a.M = B * d.P; a.N = H; a.K = m->kpe_pad; a.ldo = H; a.P = d.P; a.T = d.T; a.R = R;
+        HIP_TRY(launch_gemm(dt, EPI_PATCH, a, st));
+    }
+    const float eps = m->hp.eps;
+    for (int il = 0; il < nlayers; ++il) {
+        const LayerWeights& ly = m->layers[(size_t)il];
+        {
+            Scope sc(s, K_LAYERNORM);
+            HIP_TRY(launch_layernorm(dt, s->x, ly.norm1_w, ly.norm1_b, s->ln, d.M, H, eps, st));
+        }
+        {
+            Scope sc(s, K_QKV_GEMM);
+            GemmArgs a{};
+            a.A = s->ln; a.W = ly.qkv_w; a.bias = ly.qkv_b; a.out = s->qkv;
+            a.M = d.M; a.N = 3 * H; a.K = H; a.ldo = 3 * H; a.qcols = H; a.qscale = 0.125f;  // 1/sqrt(64), dinov2.cpp:626
+            HIP_TRY(launch_gemm(dt, EPI_QKV, a, st));
+        }
+        {
+            Scope sc(s, K_ATTENTION);
+            HIP_TRY(launch_attention(dt, s->qkv, s->att, B, d.T, H, nh, st));
+        }
+        {
+            Scope sc(s, K_OPROJ_GEMM);
+            GemmArgs a{};
+            a.A = s->att; a.W = ly.o_w; a.bias = ly.o_b; a.out = s->x; a.aux = ly.ls1;
+            a.M = d.M; a.N = H; a.K = H; a.ldo = H;
+            HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
+        }
+        {
+            Scope sc(s, K_LAYERNORM);
+            HIP_TRY(launch_layernorm(dt, s->x, ly.norm2_w, ly.norm2_b, s->ln, d.M, H, eps, st));
+        }
+        {
+            Scope sc(s, K_FC1_GEMM);
+            GemmArgs a{};
+            a.A = s->ln; a.W = ly.fc1_w; a.bias = ly.fc1_b; a.out = s->hid;
+            a.M = d.M; a.N = m->hp.swiglu ? 2 * F : F; a.K = H; a.ldo = F;
+            HIP_TRY(launch_gemm(dt, m->hp.swiglu ? EPI_SWIGLU : EPI_GELU, a, st));
+        }
+        {
+            Scope sc(s, K_FC2_GEMM);
+            GemmArgs a{};
+            a.A = s->hid; a.W = ly.fc2_w; a.bias = ly.fc2_b; a.out = s->x; a.aux = ly.ls2;
+            a.M = d.M; a.N = H; a.K = F; a.ldo = H;
+            HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
+        }
+    }
+    if (!finalize) return DINOV2_HIP_OK;
+    {
+        Scope sc(s, K_FINAL_LN);
+        HIP_TRY(launch_layernorm_f32(s->x, m->ln_w, m->ln_b, s->fin, d.M, H, eps, st));
+    }
+    if (classify) {
+        Scope sc(s, K_HEAD);
+        const int first = m->quirk_pool_regs ? 1 : 1 + R;
+        const int Mg = (int)(m->hp.img_size / m->hp.patch_size);
+        const float div = m->quirk_const_div ? (float)(Mg * Mg) : (float)(d.T - first);
+        HIP_TRY(launch_head(dt, s->fin, m->head_w, m->head_b, s->feat, s->logits, s->probs, B, d.T, H,
+                            (int)m->hp.num_classes, first, 1.0f / div, st));
+    }
+    return DINOV2_HIP_OK;
+}
+
+int check_input(const dinov2_hip_session* s, const dinov2_hip_input* in, char* err, size_t errlen) {
+    if (!s || !in || !in->data) {
+        set_err(err, errlen, "null session / input");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    const int ps = (int)s->model->hp.patch_size;
+    if (in->batch <= 0 || in->height < ps || in->width < ps || in->height % ps || in->width % ps) {
+        set_err(err, errlen, "input must be batch >= 1 and height/width positive multiples of patch_size %d (got %d x %d x %d)",
+                ps, in->batch, in->height, in->width);
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    if (in->layout != DINOV2_HIP_BGR_HWC && in->layout != DINOV2_HIP_RGB_CHW) {
+        set_err(err, errlen, "unknown input layout %d", in->layout);
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    return DINOV2_HIP_OK;
+}
+
+}  // namespace
+
+extern "C" int dinov2_hip_session_create(dinov2_hip_model* m, void* stream, dinov2_hip_session** out, char* err,
+                                         size_t errlen) {
+    if (!m || !out) {
+        set_err(err, errlen, "null argument");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(m->device));
+    std::unique_ptr<dinov2_hip_session> s(new dinov2_hip_session());
+    s->model = m;
+    if (stream) {
+        s->stream = (hipStream_t)stream;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        s->own_stream = true;
+    }
+    *out = s.release();
+    return DINOV2_HIP_OK;
+}
+
+extern "C" void dinov2_hip_session_free(dinov2_hip_session* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->model->device);
+    (void)hipStreamSynchronize(s->stream);
+    drain_profile(s);
+    for (auto e : s->free_events) (void)hipEventDestroy(e);
+    if (s->ws) (void)hipFree(s->ws);
+    if (s->own_stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" size_t dinov2_hip_workspace_bytes(const dinov2_hip_model* m, int32_t batch, int32_t height, int32_t width) {
+    if (!m || batch <= 0 || height <= 0 || width <= 0) return 0;
+    return carve_of(m, batch, height, width).total;
+}
+
+extern "C" int dinov2_hip_session_sync(dinov2_hip_session* s) {
+    if (!s) return DINOV2_HIP_ERR_INVALID;
+    return hipStreamSynchronize(s->stream) == hipSuccess ? DINOV2_HIP_OK : DINOV2_HIP_ERR_HIP;
+}
+
+extern "C" void* dinov2_hip_session_stream(dinov2_hip_session* s) { return s ? (void*)s->stream : nullptr; }
+
+extern "C" int dinov2_hip_session_profile(dinov2_hip_session* s, int32_t enable) {
+    if (!s) return DINOV2_HIP_ERR_INVALID;
+    (void)hipStreamSynchronize(s->stream);
+    drain_profile(s);
+    s->profiling = enable != 0;
+    if (enable) {
+        s->prof_ms.assign(K_COUNT, 0.0);
+        s->prof_n.assign(K_COUNT, 0);
+    }
+    return DINOV2_HIP_OK;
+}
+
+extern "C" int dinov2_hip_session_profile_read(dinov2_hip_session* s, int32_t max, const char** names, float* total_ms,
+                                               int32_t* launches) {
+    if (!s) return 0;
+    (void)hipStreamSynchronize(s->stream);
+    drain_profile(s);
+    const int n = std::min<int>(max, K_COUNT);
+    for (int i = 0; i < n; ++i) {
+        if (names) names[i] = kKindNames[i];
+        if (total_ms) total_ms[i] = (float)s->prof_ms[(size_t)i];
+        if (launches) launches[i] = s->prof_n[(size_t)i];
+    }
+    return n;
+}
+
+// =============================================================================================================
+// predict
+// =============================================================================================================
+extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input* in, dinov2_hip_output* out,
+                                  uint32_t flags, char* err, size_t errlen) {
+    int rc = check_input(s, in, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    const dinov2_hip_model* m = s->model;
+    const bool classify = (flags & DINOV2_HIP_CLASSIFY) != 0;
+    if (classify && !m->hp.has_classifier) {
+        set_err(err, errlen, "classify requested but the model was loaded without a classifier head");
+        return DINOV2_HIP_ERR_NO_HEAD;
+    }
+    if (out && out->on_device && (out->topk_ids || out->topk_probs)) {
+        set_err(err, errlen, "top-k outputs are host-only");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    const int B = in->batch, h = in->height, w = in->width;
+    rc = ensure_workspace(s, B, h, w, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    hipStream_t st = s->stream;
+
+    const float* img = in->data;
+    if (!in->on_device) {
+        HIP_TRY(hipMemcpyAsync(s->img, in->data, sizeof(float) * 3 * (size_t)B * h * w, hipMemcpyHostToDevice, st));
+        img = s->img;
+    }
+    rc = forward(s, img, B, h, w, in->layout, classify, (int)m->hp.num_hidden_layers, true, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    if (!out) return DINOV2_HIP_OK;
+
+    const Dims d = dims_of(m, B, h, w);
+    const size_t H = m->hp.hidden_size, C = m->hp.num_classes;
+    const int R = (int)m->hp.num_register_tokens;
+    const hipMemcpyKind kind = out->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t pitch = sizeof(float) * (size_t)d.T * H;
+    if (out->cls)  // "cls_token" = final-LN row 0 (dinov2.cpp:764-768)
+        HIP_TRY(hipMemcpy2DAsync(out->cls, sizeof(float) * H, s->fin, pitch, sizeof(float) * H, (size_t)B, kind, st));
+    if (out->patch_tokens) {  // rows [1+R, T) for features, [1, T) when classifying (dinov2.cpp:770-789)
+        const int first = classify ? 1 : 1 + R;
+        const size_t wbytes = sizeof(float) * (size_t)(d.T - first) * H;
+        HIP_TRY(hipMemcpy2DAsync(out->patch_tokens, wbytes, s->fin + (size_t)first * H, pitch, wbytes, (size_t)B, kind, st));
+    }
+    if (classify) {
+        if (out->logits) HIP_TRY(hipMemcpyAsync(out->logits, s->logits, sizeof(float) * B * C, kind, st));
+        if (out->probs) HIP_TRY(hipMemcpyAsync(out->probs, s->probs, sizeof(float) * B * C, kind, st));
+    }
+    if (out->on_device) return DINOV2_HIP_OK;
+
+    std::vector<float> probs_host;
+    const bool want_topk = classify && out->topk > 0 && (out->topk_ids || out->topk_probs);
+    if (want_topk) {
+        probs_host.resize((size_t)B * C);
+        HIP_TRY(hipMemcpyAsync(probs_host.data(), s->probs, sizeof(float) * B * C, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (want_topk) {  // descending sort of all classes like dinov2.cpp:961-965, ids and probabilities returned
+        const int k = std::min<int>(out->topk, (int)C);
+        std::vector<int> idx(C);
+        for (int b = 0; b < B; ++b) {
+            const float* p = probs_host.data() + (size_t)b * C;
+            std::iota(idx.begin(), idx.end(), 0);
+            std::partial_sort(idx.begin(), idx.begin() + k, idx.end(),
+                              [&](int a, int c2) { return p[a] > p[c2] || (p[a] == p[c2] && a < c2); });
+            for (int i = 0; i < out->topk; ++i) {
+                if (out->topk_ids) out->topk_ids[(size_t)b * out->topk + i] = i < k ? idx[(size_t)i] : -1;
+                if (out->topk_probs) out->topk_probs[(size_t)b * out->topk + i] = i < k ? p[idx[(size_t)i]] : 0.f;
+            }
+        }
+    }
+    return DINOV2_HIP_OK;
+}
+
+extern "C" int dinov2_hip_debug_hidden(dinov2_hip_session* s, const dinov2_hip_input* in, int32_t layer, float* out,
+                                       char* err, size_t errlen) {
+    int rc = check_input(s, in, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    const dinov2_hip_model* m = s->model;
+    if (!out || layer < 0 || layer > (int)m->hp.num_hidden_layers) {
+        set_err(err, errlen, "layer out of range");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    const int B = in->batch, h = in->height, w = in->width;
+    rc = ensure_workspace(s, B, h, w, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    const float* img = in->data;
+    if (!in->on_device) {
+        HIP_TRY(hipMemcpyAsync(s->img, in->data, sizeof(float) * 3 * (size_t)B * h * w, hipMemcpyHostToDevice, s->stream));
+        img = s->img;
+    }
+    rc = forward(s, img, B, h, w, in->layout, false, layer, false, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    const Dims d = dims_of(m, B, h, w);
+    HIP_TRY(hipMemcpyAsync(out, s->x, sizeof(float) * (size_t)d.M * m->hp.hidden_size, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return DINOV2_HIP_OK;
+}

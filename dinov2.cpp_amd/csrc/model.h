@@ -1,0 +1,64 @@
+// Host-side model / session objects behind the C-ABI (include/dinov2_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dinov2_hip.h"
+#include "kernels.h"
+
+namespace dinov2 {
+
+struct LayerWeights {
+    float *norm1_w, *norm1_b, *qkv_b, *o_b, *ls1, *norm2_w, *norm2_b, *fc1_b, *fc2_b, *ls2;
+    void *qkv_w, *o_w, *fc1_w, *fc2_w;  // compute dtype, [N, K] row-major (ggml ne = [K, N])
+};
+
+}  // namespace dinov2
+
+// replaces `struct dino_model` (/root/reference/dinov2.h:49-55): hparams + one device buffer + name->tensor map
+struct dinov2_hip_model {
+    dinov2_hip_hparams hp{};
+    dinov2::DType dt = dinov2::DT_F16;
+    int device = 0;
+    bool quirk_const_div = true, quirk_pool_regs = true;
+    int kpe = 0, kpe_pad = 0;  // patch-embed K (3*p*p) and its padding to a multiple of 64
+    char* arena = nullptr;     // ONE allocation, like model.buffer (dinov2.cpp:341)
+    size_t arena_bytes = 0;
+    std::vector<dinov2::LayerWeights> layers;
+    void* patch_w = nullptr;
+    float *patch_b = nullptr, *cls = nullptr, *pos = nullptr, *reg = nullptr, *ln_w = nullptr, *ln_b = nullptr;
+    void* head_w = nullptr;
+    float* head_b = nullptr;
+    std::vector<float> pos_host;  // the reference reads position_embeddings on the host every call (dinov2.cpp:935-938)
+    std::vector<std::string> labels;
+};
+
+struct ProfRecord {
+    int kind;
+    hipEvent_t a, b;
+};
+
+// replaces the caller-owned ggml_gallocr_t (/root/reference/dinov2.h:111-112): stream + workspace + cached pos-embed
+struct dinov2_hip_session {
+    dinov2_hip_model* model = nullptr;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // carved views (valid for cur_* shape)
+    int cur_b = 0, cur_h = 0, cur_w = 0;
+    float *img = nullptr, *x = nullptr, *fin = nullptr, *feat = nullptr, *logits = nullptr, *probs = nullptr,
+          *pos = nullptr;
+    void *col = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    int pos_h = -1, pos_w = -1;  // grid the cached interpolated pos-embed in `pos` belongs to
+    std::vector<float> pos_stage;
+    // profiling
+    bool profiling = false;
+    std::vector<ProfRecord> records;
+    std::vector<hipEvent_t> free_events;
+    std::vector<double> prof_ms;
+    std::vector<int> prof_n;
+};

@@ -1,0 +1,156 @@
+// Diagnostic entry points (include/dinov2_hip_ops.h): run ONE kernel on host-provided f32 data so that the parity
+// tests can check each hand-written kernel against the oracle / numpy in isolation.  Not used by predict.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <vector>
+
+#include "../../include/dinov2_hip_ops.h"
+#include "kernels.h"
+
+using namespace dinov2;
+
+namespace {
+
+template <typename T>
+std::vector<T> to_t(const float* src, size_t n) {
+    std::vector<T> v(n);
+    for (size_t i = 0; i < n; ++i) v[i] = (T)src[i];
+    return v;
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+};
+
+#define OP_TRY(x)                          \
+    do {                                   \
+        if ((x) != hipSuccess) return -1;  \
+    } while (0)
+
+hipError_t upload_as(DType dt, const float* src, size_t n, DevBuf& d) {
+    hipError_t e = d.alloc(n * 2);
+    if (e != hipSuccess) return e;
+    if (dt == DT_F16) {
+        auto v = to_t<_Float16>(src, n);
+        return hipMemcpy(d.p, v.data(), n * 2, hipMemcpyHostToDevice);
+    }
+    auto v = to_t<__bf16>(src, n);
+    return hipMemcpy(d.p, v.data(), n * 2, hipMemcpyHostToDevice);
+}
+
+hipError_t download_as(DType dt, const void* dev, size_t n, float* dst) {
+    std::vector<uint16_t> raw(n);
+    hipError_t e = hipMemcpy(raw.data(), dev, n * 2, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return e;
+    for (size_t i = 0; i < n; ++i) {
+        if (dt == DT_F16) {
+            _Float16 h;
+            std::memcpy(&h, &raw[i], 2);
+            dst[i] = (float)h;
+        } else {
+            uint32_t u = (uint32_t)raw[i] << 16;
+            std::memcpy(&dst[i], &u, 4);
+        }
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int dinov2_hip_op_gemm(int32_t dtype, int32_t epilogue, const float* A, const float* W, const float* bias,
+                                  const float* aux, int64_t aux_count, float* out, int32_t out_rows, int32_t ldo,
+                                  int32_t M, int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols,
+                                  float qscale) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    if (gemm_init() != hipSuccess) return -1;
+    DevBuf dA, dW, dB, dX, dO;
+    OP_TRY(upload_as(dt, A, (size_t)M * K, dA));
+    OP_TRY(upload_as(dt, W, (size_t)N * K, dW));
+    if (bias) {
+        OP_TRY(dB.alloc(sizeof(float) * N));
+        OP_TRY(hipMemcpy(dB.p, bias, sizeof(float) * N, hipMemcpyHostToDevice));
+    }
+    if (aux) {
+        OP_TRY(dX.alloc(sizeof(float) * (size_t)aux_count));
+        OP_TRY(hipMemcpy(dX.p, aux, sizeof(float) * (size_t)aux_count, hipMemcpyHostToDevice));
+    }
+    const bool f32out = epilogue == EPI_PATCH || epilogue == EPI_RESID || epilogue == EPI_PLAIN_F32;
+    const size_t on = (size_t)out_rows * ldo;
+    OP_TRY(dO.alloc(on * 4));
+    if (f32out) OP_TRY(hipMemcpy(dO.p, out, on * 4, hipMemcpyHostToDevice));
+    else OP_TRY(hipMemset(dO.p, 0, on * 4));
+    GemmArgs a{};
+    a.A = dA.p; a.W = dW.p; a.bias = (const float*)dB.p; a.out = dO.p; a.aux = (const float*)dX.p;
+    a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.P = P; a.T = T; a.R = R; a.qcols = qcols; a.qscale = qscale;
+    OP_TRY(launch_gemm(dt, (Epilogue)epilogue, a, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    if (f32out) OP_TRY(hipMemcpy(out, dO.p, on * 4, hipMemcpyDeviceToHost));
+    else OP_TRY(download_as(dt, dO.p, on, out));
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_attention(int32_t dtype, const float* qkv, float* out, int32_t B, int32_t T, int32_t H,
+                                       int32_t nh) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    DevBuf dQ, dO;
+    const size_t nq = (size_t)B * T * 3 * H, no = (size_t)B * T * H;
+    OP_TRY(upload_as(dt, qkv, nq, dQ));
+    OP_TRY(dO.alloc(no * 2));
+    OP_TRY(hipMemset(dO.p, 0, no * 2));
+    OP_TRY(launch_attention(dt, dQ.p, dO.p, B, T, H, nh, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(download_as(dt, dO.p, no, out));
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_layernorm(int32_t dtype, const float* x, const float* w, const float* b, float* out,
+                                       int32_t rows, int32_t H, float eps) {
+    DevBuf dX, dW, dB, dO;
+    const size_t n = (size_t)rows * H;
+    OP_TRY(dX.alloc(n * 4));
+    OP_TRY(dW.alloc((size_t)H * 4));
+    OP_TRY(dB.alloc((size_t)H * 4));
+    OP_TRY(dO.alloc(n * 4));
+    OP_TRY(hipMemcpy(dX.p, x, n * 4, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(dW.p, w, (size_t)H * 4, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(dB.p, b, (size_t)H * 4, hipMemcpyHostToDevice));
+    if (dtype < 0) {
+        OP_TRY(launch_layernorm_f32((const float*)dX.p, (const float*)dW.p, (const float*)dB.p, (float*)dO.p, rows, H, eps,
+                                    nullptr));
+        OP_TRY(hipDeviceSynchronize());
+        OP_TRY(hipMemcpy(out, dO.p, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+        OP_TRY(launch_layernorm(dt, (const float*)dX.p, (const float*)dW.p, (const float*)dB.p, dO.p, rows, H, eps, nullptr));
+        OP_TRY(hipDeviceSynchronize());
+        OP_TRY(download_as(dt, dO.p, n, out));
+    }
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_convert_weight(int32_t dtype, const void* src, uint64_t src_bytes, uint32_t ggml_type,
+                                            float* out, int32_t N, int32_t K, int32_t Kpad, int32_t interleaveF) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    DevBuf dS, dO;
+    OP_TRY(dS.alloc(src_bytes));
+    OP_TRY(hipMemcpy(dS.p, src, src_bytes, hipMemcpyHostToDevice));
+    OP_TRY(dO.alloc((size_t)N * Kpad * 2));
+    OP_TRY(launch_convert_weight(dt, dS.p, ggml_type, dO.p, N, K, Kpad, interleaveF, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(download_as(dt, dO.p, (size_t)N * Kpad, out));
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_probe_tr16(int16_t* out256) {
+    DevBuf d;
+    OP_TRY(d.alloc(512));
+    OP_TRY(launch_probe_tr16((int16_t*)d.p, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(hipMemcpy(out256, d.p, 512, hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,145 @@
+/*
+ * dinov2_hip.h -- C-ABI of the MI355X-native DINOv2 forward (libdinov2_hip.so).
+ *
+ * Drop-in boundary for the hot path of lavaman131/dinov2.cpp: everything the reference does between
+ * `dino_model_load` and the return of `dino_predict`.  Plain pointers and sizes only: no ggml, OpenCV,
+ * torch or C++ types cross this boundary.  Every entry point cites the reference interface it replaces
+ * (paths relative to the reference repo).  Status codes, never abort/assert/throw (the reference mixes
+ * bool / empty unique_ptr / assert / exceptions: dinov2.cpp:58,269-272,945-948).
+ *
+ * Threading: a model is immutable after load and may be shared by any number of sessions; one session
+ * = one HIP stream + one workspace and is used by one host thread at a time (the role the caller-owned
+ * `ggml_gallocr_t allocr` plays in dinov2.h:111-112).
+ */
+#ifndef DINOV2_HIP_H
+#define DINOV2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINOV2_HIP_ABI_VERSION 1
+
+typedef struct dinov2_hip_model dinov2_hip_model;     /* replaces `struct dino_model`     dinov2.h:49-55   */
+typedef struct dinov2_hip_session dinov2_hip_session; /* replaces `ggml_gallocr_t allocr` dinov2.h:111-112 */
+
+enum dinov2_hip_status {
+    DINOV2_HIP_OK = 0,
+    DINOV2_HIP_ERR_IO = 1,          /* file cannot be opened / short read   (dinov2.cpp:269-272 returns false) */
+    DINOV2_HIP_ERR_FORMAT = 2,      /* not GGUF, missing KV or tensor       (dinov2.cpp:58 asserts)            */
+    DINOV2_HIP_ERR_UNSUPPORTED = 3, /* tensor type / shape outside the DINOv2 family                            */
+    DINOV2_HIP_ERR_INVALID = 4,     /* bad argument                                                             */
+    DINOV2_HIP_ERR_HIP = 5,         /* HIP runtime error (message carries hipGetErrorString)                    */
+    DINOV2_HIP_ERR_NO_HEAD = 6      /* classify requested on a model loaded without a classifier                */
+};
+
+enum dinov2_hip_dtype { DINOV2_HIP_F16 = 0, DINOV2_HIP_BF16 = 1 };
+
+/* Input image memory layouts accepted by dinov2_hip_predict. */
+enum dinov2_hip_layout {
+    DINOV2_HIP_BGR_HWC = 0, /* continuous CV_32FC3 cv::Mat as handed to dino_predict (dinov2.cpp:900, 914-931) */
+    DINOV2_HIP_RGB_CHW = 1  /* the planar "input" tensor dino_predict uploads        (dinov2.cpp:629-631, 933) */
+};
+
+/* predict flags */
+#define DINOV2_HIP_CLASSIFY 1u /* dino_params.classify (dinov2.h:63): run forward_head, patch view includes registers */
+
+typedef struct dinov2_hip_load_opts {
+    int32_t device;        /* HIP device ordinal (the reference picks its backend by #ifdef, dinov2.cpp:241-261)   */
+    int32_t compute_dtype; /* enum dinov2_hip_dtype: MFMA input type of every weight GEMM and of attention          */
+    int32_t classify;      /* dino_params.classify at load: read labels + classifier (dinov2.cpp:297-305)           */
+    int32_t skip_tensor_data; /* 1: parse metadata and allocate the arena but leave it unfilled -- for ranks that
+                                 receive the arena by RCCL broadcast (dinov2_hip_model_arena)                        */
+    int32_t quirk_pool_const_divisor;      /* 1 (default): pooled = sum / (img_size/patch)^2  (dinov2.cpp:794,800-803) */
+    int32_t quirk_pool_includes_registers; /* 1 (default): register tokens are pooled too      (dinov2.cpp:772-776)     */
+    int32_t reserved[10];
+} dinov2_hip_load_opts;
+
+/* dino_hparams (dinov2.h:25-47) plus what the loader derives from the tensor list. */
+typedef struct dinov2_hip_hparams {
+    uint32_t hidden_size, num_hidden_layers, num_attention_heads, num_classes;
+    uint32_t num_register_tokens, patch_size, img_size, ftype;
+    float eps;             /* 1e-6 (dinov2.h:33; dino_params.eps is unused by the reference) */
+    uint32_t ffn_hidden;   /* fc1 rows, or weights_out columns for SwiGLU                                */
+    uint32_t swiglu;       /* reference selects by num_hidden_layers == 40 (dinov2.cpp:740); here: tensor presence */
+    uint32_t has_classifier;
+    uint32_t weight_type;  /* ggml type id of the 2-D weights as stored in the file (1 f16, 8 q8_0, ...)  */
+    uint32_t compute_dtype;
+} dinov2_hip_hparams;
+
+typedef struct dinov2_hip_input {
+    const float *data; /* [batch] images, f32, already preprocessed (dino_preprocess output)               */
+    int32_t batch;     /* the reference is batch 1 (dinov2.cpp:630); B images = B independent forwards     */
+    int32_t height;    /* multiples of patch_size, like img.size() in dinov2.cpp:908                       */
+    int32_t width;
+    int32_t layout;    /* enum dinov2_hip_layout                                                           */
+    int32_t on_device; /* 0: host memory (copied H2D each call); 1: device memory on the model's device    */
+} dinov2_hip_input;
+
+/* Caller-allocated outputs; any pointer may be NULL.  Printing top-k stays in the caller. */
+typedef struct dinov2_hip_output {
+    float *cls;          /* [B, H]            "cls_token"    dinov2.cpp:764-768                                   */
+    float *patch_tokens; /* [B, P, H] features; [B, R+P, H] with CLASSIFY ("patch_tokens", dinov2.cpp:770-789);
+                            row = patch index y*w0+x like the cv::Mat of dinov2.cpp:979-992                        */
+    float *logits;       /* [B, C]            unnamed tensor of dinov2.cpp:811-812 (CLASSIFY only)                */
+    float *probs;        /* [B, C]            "probs"        dinov2.cpp:815-820  (CLASSIFY only)                  */
+    int32_t *topk_ids;   /* [B, topk]         sorted descending like dinov2.cpp:961-965 (CLASSIFY only)           */
+    float *topk_probs;   /* [B, topk]         (the reference's preds[] holds uint32(prob) == 0, dinov2.cpp:975)   */
+    int32_t topk;        /* dino_params.topk (dinov2.h:59)                                                        */
+    int32_t on_device;   /* 0: host pointers (call returns after the copy-out); 1: device pointers, async         */
+} dinov2_hip_output;
+
+/* -- load (replaces dino_model_load, dinov2.h:98-99 / dinov2.cpp:239-352) ---------------------------- */
+void dinov2_hip_default_load_opts(dinov2_hip_load_opts *opts);
+int dinov2_hip_model_load(const char *gguf_path, const dinov2_hip_load_opts *opts, dinov2_hip_model **out,
+                          char *err, size_t errlen);
+/* replaces the caller-side frees of inference.cpp:70-73 */
+void dinov2_hip_model_free(dinov2_hip_model *model);
+/* replaces reads of model.hparams (dinov2.cpp:276-299) */
+int dinov2_hip_model_hparams(const dinov2_hip_model *model, dinov2_hip_hparams *out);
+/* replaces model.hparams.id2label.at(id) (dinov2.cpp:301-305, 972); NULL when out of range */
+const char *dinov2_hip_model_label(const dinov2_hip_model *model, int32_t id);
+/* The packed device weight arena (one allocation, like model.buffer of dinov2.cpp:341): lets a multi-GPU
+ * host broadcast rank 0's converted weights over RCCL/xGMI instead of re-reading the GGUF 8 times. */
+int dinov2_hip_model_arena(dinov2_hip_model *model, void **device_ptr, size_t *bytes);
+
+/* -- session (replaces ggml_gallocr_new / reuse across calls, inference.cpp:63, realtime.cpp:62) ---- */
+/* `stream`: a hipStream_t to run on, or NULL to let the session create its own. */
+int dinov2_hip_session_create(dinov2_hip_model *model, void *stream, dinov2_hip_session **out, char *err,
+                              size_t errlen);
+void dinov2_hip_session_free(dinov2_hip_session *session);
+/* Bytes of device workspace one predict of this shape needs (cf. ggml_gallocr_alloc_graph, dinov2.cpp:910). */
+size_t dinov2_hip_workspace_bytes(const dinov2_hip_model *model, int32_t batch, int32_t height, int32_t width);
+/* Blocks until everything enqueued on the session's stream has finished (ggml_backend_synchronize,
+ * inference.cpp:66). */
+int dinov2_hip_session_sync(dinov2_hip_session *session);
+void *dinov2_hip_session_stream(dinov2_hip_session *session);
+
+/* -- predict (replaces dino_predict, dinov2.h:111-112 / dinov2.cpp:900-999) -------------------------- */
+int dinov2_hip_predict(dinov2_hip_session *session, const dinov2_hip_input *in, dinov2_hip_output *out,
+                       uint32_t flags, char *err, size_t errlen);
+
+/* Host helper, exposed for parity tests: interpolate_pos_embed (dinov2.h:101-103 / dinov2.cpp:159-225).
+ * out: [(1 + h_new*w_new), H] f32. */
+int dinov2_hip_interpolate_pos_embed(const dinov2_hip_model *model, int32_t h_new, int32_t w_new, float *out);
+
+/* -- measurement hooks (no reference counterpart; the reference times the whole call, inference.cpp:64-68) */
+/* Per-kernel-kind HIP-event timing of subsequent predicts on this session (adds two events per launch). */
+int dinov2_hip_session_profile(dinov2_hip_session *session, int32_t enable);
+/* Accumulated since enable: for kind k in [0, n): name, total ms, launches.  Returns n (<= max). */
+int dinov2_hip_session_profile_read(dinov2_hip_session *session, int32_t max, const char **names, float *total_ms,
+                                    int32_t *launches);
+/* Debug/parity: copy the f32 token stream [B, T, H] as it stands after `layer` layers (0 = embeddings) of the
+ * LAST predict with the same shape re-run up to that point.  Host pointer. */
+int dinov2_hip_debug_hidden(dinov2_hip_session *session, const dinov2_hip_input *in, int32_t layer, float *out,
+                            char *err, size_t errlen);
+
+int dinov2_hip_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINOV2_HIP_H */

@@ -1,0 +1,42 @@
+/*
+ * dinov2_hip_ops.h -- diagnostic single-kernel entry points of libdinov2_hip.so.
+ *
+ * NOT part of the drop-in boundary (that is include/dinov2_hip.h).  These run one hand-written kernel on host f32
+ * data (converted to the compute dtype on the way in, back to f32 on the way out) so the parity tests can check each
+ * kernel against the oracle in isolation -- the per-op granularity the reference gets from ggml's own op tests and
+ * that /root/reference itself never had (it holds no tests at all).  All return 0 on success, -1 on a HIP error.
+ */
+#ifndef DINOV2_HIP_OPS_H
+#define DINOV2_HIP_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* epilogue ids (csrc/kernels.h): 0 patch-embed(+bias+pos, token scatter) 1 qkv(+bias, q scaled) 2 residual
+ * (x += ls*(acc+bias)) 3 gelu 4 swiglu 5 plain f32.  Replaces ggml_mul_mat call sites of dinov2.cpp:471,546,561,570,
+ * 582,608,636 with their trailing elementwise nodes.  `out` is [out_rows, ldo] f32, read first for epilogues 0/2/5. */
+int dinov2_hip_op_gemm(int32_t dtype, int32_t epilogue, const float *A, const float *W, const float *bias,
+                       const float *aux, int64_t aux_count, float *out, int32_t out_rows, int32_t ldo, int32_t M,
+                       int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols, float qscale);
+
+/* fused attention over token-major qkv [B*T, 3H] (q already scaled) -> [B*T, H]; replaces dinov2.cpp:479-543 */
+int dinov2_hip_op_attention(int32_t dtype, const float *qkv, float *out, int32_t B, int32_t T, int32_t H, int32_t nh);
+
+/* ggml_norm * w + b (dinov2.cpp:694-700); dtype -1 = f32 output (final layernorm), 0/1 = f16/bf16 output */
+int dinov2_hip_op_layernorm(int32_t dtype, const float *x, const float *w, const float *b, float *out, int32_t rows,
+                            int32_t H, float eps);
+
+/* load-time tensor conversion / dequantisation (F32,F16,BF16,Q4_0,Q4_1,Q5_0,Q5_1,Q8_0 -> compute dtype) */
+int dinov2_hip_op_convert_weight(int32_t dtype, const void *src, uint64_t src_bytes, uint32_t ggml_type, float *out,
+                                 int32_t N, int32_t K, int32_t Kpad, int32_t interleaveF);
+
+/* what ds_read_b64_tr_b16 hands each lane for addr = lane*8 over an LDS image of its own indices: out[64][4] */
+int dinov2_hip_op_probe_tr16(int16_t *out256);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINOV2_HIP_OPS_H */

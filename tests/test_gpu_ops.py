@@ -1,0 +1,222 @@
+"""Per-kernel parity on the GPU: each hand-written HIP kernel, called through the C-ABI diagnostic entry points
+(include/dinov2_hip_ops.h), against a numpy restatement of the ggml op it replaces."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F16, BF16 = 0, 1
+EPI_PATCH, EPI_QKV, EPI_RESID, EPI_GELU, EPI_SWIGLU, EPI_PLAIN = range(6)
+fp = C.POINTER(C.c_float)
+
+
+def _p(a):
+    return a.ctypes.data_as(fp) if a is not None else fp()
+
+
+def _round(a, dt):
+    a = np.asarray(a, np.float32)
+    if dt == F16:
+        return a.astype(np.float16).astype(np.float32)
+    u = a.view(np.uint32)
+    u = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
+    return u.view(np.float32)
+
+
+def _gemm(api, dt, epi, A, W, bias, aux, out, M, N, K, ldo, P=0, T=0, R=0, qcols=0, qscale=1.0):
+    rc = api.lib().dinov2_hip_op_gemm(dt, epi, _p(A), _p(W), _p(bias), _p(aux), 0 if aux is None else aux.size, _p(out),
+                                      out.shape[0], ldo, M, N, K, P, T, R, qcols, qscale)
+    assert rc == 0
+    return out
+
+
+def test_tr16_lane_mapping(api):
+    """ds_read_b64_tr_b16: lane l of 16-lane group g gets column (l & 15) of the 4x16 block its group addresses."""
+    out = np.zeros((64, 4), np.int16)
+    assert api.lib().dinov2_hip_op_probe_tr16(out.ctypes.data_as(C.POINTER(C.c_int16))) == 0
+    lanes = np.arange(64)
+    exp = (64 * (lanes >> 4))[:, None] + 16 * np.arange(4)[None, :] + (lanes & 15)[:, None]
+    assert np.array_equal(out, exp), f"unexpected tr16 mapping:\n{out}"
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("M,N,K", [(300, 384, 128), (77, 128, 640), (12300, 1024, 256), (1374, 1000, 192)])
+def test_gemm_plain(api, dt, M, N, K):
+    """mul_mat(W, x) + bias with asymmetric operands (catches transposed fragments), M/N edge tiles, both tile configs."""
+    rng = np.random.default_rng(M + N + K + dt)
+    A = _round(rng.standard_normal((M, K)), dt)
+    W = _round(rng.standard_normal((N, K)) * 0.1 + np.linspace(-0.2, 0.3, N)[:, None], dt)
+    bias = rng.standard_normal(N).astype(np.float32)
+    out = np.full((M, N), np.nan, np.float32)
+    _gemm(api, dt, EPI_PLAIN, A, W, bias, None, out, M, N, K, N)
+    ref = (A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32)
+    assert np.isfinite(out).all()
+    np.testing.assert_allclose(out, ref, rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_gemm_qkv_epilogue(api, dt):
+    M, H, K = 500, 128, 128
+    rng = np.random.default_rng(1)
+    A, W = _round(rng.standard_normal((M, K)), dt), _round(rng.standard_normal((3 * H, K)) * 0.1, dt)
+    bias = rng.standard_normal(3 * H).astype(np.float32)
+    out = np.zeros((M, 3 * H), np.float32)
+    _gemm(api, dt, EPI_QKV, A, W, bias, None, out, M, 3 * H, K, 3 * H, qcols=H, qscale=0.125)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    ref[:, :H] *= 0.125
+    ref = _round(ref.astype(np.float32), dt)
+    tol = 2e-3 if dt == F16 else 1.6e-2  # one output ulp
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_gemm_residual_epilogue(api, dt):
+    M, N, K = 700, 256, 512
+    rng = np.random.default_rng(2)
+    A, W = _round(rng.standard_normal((M, K)), dt), _round(rng.standard_normal((N, K)) * 0.05, dt)
+    bias, ls = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    x0 = rng.standard_normal((M, N)).astype(np.float32)
+    out = x0.copy()
+    _gemm(api, dt, EPI_RESID, A, W, bias, ls, out, M, N, K, N)
+    ref = x0 + ls * (A.astype(np.float64) @ W.astype(np.float64).T + bias)
+    np.testing.assert_allclose(out, ref.astype(np.float32), rtol=2e-5, atol=2e-4)
+
+
+def test_gemm_gelu_epilogue_matches_ggml_f16_lut(api):
+    """ggml_gelu = f16 LUT: table[f16(x)] = f16(gelu_tanh(f32(f16(x)))), x <= -10 -> 0, x >= 10 -> x."""
+    M, N, K = 300, 256, 64
+    rng = np.random.default_rng(3)
+    A = _round(rng.standard_normal((M, K)) * 2.0, F16)
+    W = _round(rng.standard_normal((N, K)) * 0.4, F16)
+    bias = (rng.standard_normal(N) * 3).astype(np.float32)
+    out = np.zeros((M, N), np.float32)
+    _gemm(api, F16, EPI_GELU, A, W, bias, None, out, M, N, K, N)
+    h = (A.astype(np.float64) @ W.astype(np.float64).T + bias).astype(np.float32)
+    xr = h.astype(np.float16).astype(np.float64)
+    g = 0.5 * xr * (1 + np.tanh(0.79788456080286535587989211986876 * xr * (1 + 0.044715 * xr * xr)))
+    g = g.astype(np.float32).astype(np.float16).astype(np.float32)
+    ref = np.where(h <= -10, 0, np.where(h >= 10, h, g)).astype(np.float16).astype(np.float32)
+    # the f32 pre-activation differs by accumulation order, so f16(x) may flip by one ulp near a rounding boundary
+    diff = np.abs(out - ref)
+    assert (diff > 2e-3 * np.maximum(1, np.abs(ref))).mean() < 1e-3
+    assert diff.max() <= 4e-3 * max(1.0, np.abs(ref).max())
+    assert np.abs(h).max() > 10  # the |x| >= 10 branches are exercised
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+def test_gemm_swiglu_epilogue(api, dt):
+    """weights_in rows interleaved in 32-blocks x1|x2 (done by the loader); out = silu(x1) * x2."""
+    M, F, K = 400, 256, 128
+    rng = np.random.default_rng(4)
+    A = _round(rng.standard_normal((M, K)), dt)
+    Win = _round(rng.standard_normal((2 * F, K)) * 0.2, dt)  # [x1 ; x2] like the GGUF tensor
+    bin_ = rng.standard_normal(2 * F).astype(np.float32)
+    n = np.arange(2 * F)
+    src = ((n >> 5) & 1) * F + (n >> 6) * 32 + (n & 31)
+    out = np.zeros((M, F), np.float32)
+    _gemm(api, dt, EPI_SWIGLU, A, np.ascontiguousarray(Win[src]), np.ascontiguousarray(bin_[src]), None, out, M, 2 * F, K, F)
+    h = A.astype(np.float64) @ Win.astype(np.float64).T + bin_
+    x1, x2 = h[:, :F], h[:, F:]
+    ref = _round((x1 / (1 + np.exp(-x1)) * x2).astype(np.float32), dt)
+    tol = 2e-3 if dt == F16 else 1.6e-2
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+
+
+def test_gemm_patch_epilogue(api):
+    """patch-embed GEMM: + bias + pos_embed[1 + p], scattered to token rows 1 + R + p of each image."""
+    B, P, R, H, K = 3, 24, 4, 128, 640
+    T = 1 + R + P
+    rng = np.random.default_rng(5)
+    A, W = _round(rng.standard_normal((B * P, K)), F16), _round(rng.standard_normal((H, K)) * 0.1, F16)
+    bias = rng.standard_normal(H).astype(np.float32)
+    pos = rng.standard_normal((1 + P, H)).astype(np.float32)
+    x = np.full((B * T, H), 7.0, np.float32)
+    _gemm(api, F16, EPI_PATCH, A, W, bias, pos, x, B * P, H, K, H, P=P, T=T, R=R)
+    ref = np.full((B, T, H), 7.0, np.float32)
+    c = (A.astype(np.float64) @ W.astype(np.float64).T + bias).reshape(B, P, H)
+    ref[:, 1 + R:] = c + pos[1:]
+    np.testing.assert_allclose(x.reshape(B, T, H), ref, rtol=2e-5, atol=2e-4)
+
+
+def _attn_ref(qkv, B, T, H, nh, dt):
+    q, k, v = (qkv.reshape(B, T, 3, nh, 64)[:, :, i].transpose(0, 2, 1, 3).astype(np.float64) for i in range(3))
+    s = q @ k.transpose(0, 1, 3, 2)
+    s -= s.max(-1, keepdims=True)
+    p = np.exp(s)
+    o = (p / p.sum(-1, keepdims=True)) @ v
+    return o.transpose(0, 2, 1, 3).reshape(B * T, H)
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("B,T,nh", [(2, 200, 2), (1, 1374, 1), (1, 64, 3), (1, 37, 1), (2, 129, 2)])
+def test_attention(api, dt, B, T, nh):
+    """soft_max_ext(K^T Q) V per head; T not a multiple of 64 exercises the masked key tail, T % 128 the query tail."""
+    H = nh * 64
+    rng = np.random.default_rng(T + nh)
+    qkv = rng.standard_normal((B * T, 3 * H)).astype(np.float32)
+    qkv[:, :H] *= 0.5  # plays the role of the pre-scaled q
+    qkv[:, 2 * H:] += np.linspace(-1, 1, H)  # asymmetric V columns
+    qkv = _round(qkv, dt)
+    out = np.zeros((B * T, H), np.float32)
+    assert api.lib().dinov2_hip_op_attention(dt, _p(qkv), _p(out), B, T, H, nh) == 0
+    ref = _attn_ref(qkv, B, T, H, nh, dt)
+    tol = 3e-3 if dt == F16 else 2.5e-2
+    assert np.isfinite(out).all()
+    np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
+
+
+def test_attention_online_softmax_rescale(api):
+    """Force the running-max update late in the key sequence: one query gets a spike on a key in the LAST tile."""
+    B, T, nh, H = 1, 300, 1, 64
+    rng = np.random.default_rng(9)
+    qkv = (rng.standard_normal((T, 3 * H)) * 0.3).astype(np.float32)
+    qkv[5, :H] = 0.0
+    qkv[5, 0] = 6.0          # query 5
+    qkv[290, H + 0] = 8.0    # key 290 -> score 48 vs O(1) elsewhere
+    qkv = _round(qkv, F16)
+    out = np.zeros((T, H), np.float32)
+    assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
+    ref = _attn_ref(qkv, B, T, H, nh, F16)
+    np.testing.assert_allclose(out, ref, rtol=3e-3, atol=3e-3)
+    np.testing.assert_allclose(out[5], qkv[290, 2 * H:], rtol=2e-3, atol=2e-3)  # query 5 attends key 290 only
+
+
+@pytest.mark.parametrize("H", [128, 384, 768, 1024, 1536])
+def test_layernorm(api, H):
+    rows = 301
+    rng = np.random.default_rng(H)
+    x = (rng.standard_normal((rows, H)) * 3 + rng.standard_normal((rows, 1)) * 5).astype(np.float32)
+    w, b = (1 + 0.2 * rng.standard_normal(H)).astype(np.float32), rng.standard_normal(H).astype(np.float32)
+    x64 = x.astype(np.float64)
+    mu = x64.mean(-1, keepdims=True)
+    ref = (x64 - mu) / np.sqrt(((x64 - mu) ** 2).mean(-1, keepdims=True) + 1e-6) * w + b
+    out = np.zeros((rows, H), np.float32)
+    assert api.lib().dinov2_hip_op_layernorm(-1, _p(x), _p(w), _p(b), _p(out), rows, H, 1e-6) == 0
+    np.testing.assert_allclose(out, ref, rtol=1e-5, atol=1e-5)
+    assert api.lib().dinov2_hip_op_layernorm(F16, _p(x), _p(w), _p(b), _p(out), rows, H, 1e-6) == 0
+    np.testing.assert_allclose(out, ref.astype(np.float32).astype(np.float16).astype(np.float32), rtol=1.5e-3, atol=1.5e-3)
+
+
+@pytest.mark.parametrize("tname", ["f32", "f16", "q8_0", "q4_0", "q4_1", "q5_0", "q5_1"])
+def test_convert_weight_dequant(api, pkg, tname):
+    """Dequant-on-load kernel vs the oracle's numpy block decoder: bit-exact after the f16 rounding."""
+    from oracle import gguf_np as G
+    gw = pkg.gguf_writer
+    N, K, Kpad = 96, 160, 192
+    rng = np.random.default_rng(11)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    gt = gw.NAME_TYPE[tname]
+    if tname == "f32":
+        raw, ref = w.tobytes(), w
+    elif tname == "f16":
+        raw, ref = w.astype(np.float16).tobytes(), w.astype(np.float16).astype(np.float32)
+    else:
+        q = gw.quantize(w, gt)
+        raw, ref = q.tobytes(), G.dequantize(q, gt, (N, K))
+    out = np.zeros((N, Kpad), np.float32)
+    buf = (C.c_char * len(raw)).from_buffer_copy(raw)
+    assert api.lib().dinov2_hip_op_convert_weight(F16, C.cast(buf, C.c_void_p), len(raw), gt, _p(out), N, K, Kpad, 0) == 0
+    assert np.array_equal(out[:, :K], ref.astype(np.float16).astype(np.float32))
+    assert not out[:, K:].any()
