@@ -19,7 +19,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdinov2_hip.so")
+LIB_PATH = os.environ.get("DINOV2_HIP_LIB") or os.path.join(_HERE, "libdinov2_hip.so")  # env override: tuning variants only
 
 F16, BF16 = 0, 1
 BGR_HWC, RGB_CHW = 0, 1
@@ -114,6 +114,10 @@ def lib():
     L.dinov2_hip_op_layernorm.argtypes = [i32, fp, fp, fp, fp, i32, i32, C.c_float]
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_probe_tr16.argtypes = [C.POINTER(C.c_int16)]
+    L.dinov2_hip_op_gemm_bench.argtypes = [i32] * 6
+    L.dinov2_hip_op_gemm_bench.restype = C.c_float
+    L.dinov2_hip_op_attention_bench.argtypes = [i32] * 6
+    L.dinov2_hip_op_attention_bench.restype = C.c_float
     _lib = L
     return L
 

@@ -11,6 +11,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define DINO_GLOBAL_AS __attribute__((address_space(1)))
 #define DINO_LDS_AS __attribute__((address_space(3)))

@@ -16,8 +16,15 @@
 //     again on the ds_read address: 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7), which makes every
 //     16-lane ds_read_b128 group hit 16 distinct bank slots.
 //   * 1-D grid with an XCD-aware remap so tiles that share an A row-panel run on the same XCD (shared L2).
+#include <cstdlib>
+
 #include "device_types.h"
 #include "kernels.h"
+
+// tuning aid, compile-time only (make variants): 1 = skip epilogue, 2 = skip in-loop staging, 4 = skip MFMA
+#ifndef DINO_GEMM_DBG
+#define DINO_GEMM_DBG 0
+#endif
 
 namespace dinov2 {
 
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         // one barrier per K tile: (a) every wave's loads of tile kt have landed (vmcnt(0) precedes the barrier),
         // (b) every wave is done reading the buffer tile kt+1 is about to overwrite
         __syncthreads();
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        if (kt + 1 < nk && !(DINO_GEMM_DBG & 2)) stage((kt + 1) & 1, kt + 1);
         const char* s = smem + (kt & 1) * STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -111,7 +118,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < MREP; ++i)
 #pragma unroll
-                for (int j = 0; j < NREP; ++j) acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < NREP; ++j) {
+                    if constexpr ((DINO_GEMM_DBG & 4) != 0) acc[i][j][0] += (float)af[i][0] * (float)bf[j][0];
+                    else acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+                }
         }
     }
 
@@ -119,6 +129,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     //      row = m0 + wm*WTM + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),  col = n0 + wn*WTN + j*32 + (lane&31)
     const int colb = n0 + wn * WTN + fr;
     const int rowb = m0 + wm * WTM + 4 * fh;
+    if ((DINO_GEMM_DBG & 1) && acc[0][0][0] != 12345.678f) return;
 
     if constexpr (EPI == EPI_SWIGLU) {
         // W rows interleaved in 32-blocks: n-block 2q holds x1[32q..], n-block 2q+1 holds x2[32q..]
@@ -229,28 +240,34 @@ static hipError_t set_attr_cfg() {
     return e;
 }
 
+hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);  // gemm2.hip
+hipError_t gemm2_init();
+
 hipError_t gemm_init() {
-    hipError_t e = set_attr_cfg<_Float16, 256, 256, 2, 4>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 256, 256, 2, 4>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 128, 128, 2, 2>();
+    hipError_t e = set_attr_cfg<_Float16, 128, 128, 2, 2>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 128, 128, 2, 2>();
+    if (e == hipSuccess) e = gemm2_init();
     return e;
 }
 
-// Tile choice: 256x256 needs N % 256 == 0 (QKV blocks must not straddle q|k|v, SwiGLU pairs must not straddle a
-// tile) and enough tiles to fill 256 CUs; otherwise 128x128 (N % 128 == 0 for the same reasons, else edge-guarded).
+// Kernel choice: the 256x256 kernel (gemm2.hip) needs N % 256 == 0 (tiles must not straddle q|k|v or a SwiGLU pair,
+// and it has no N edge guards) and enough tiles to fill the 256 CUs; everything else takes the 128x128 kernel here.
 static bool use_big_tile(const GemmArgs& a) {
-    if (a.N % 256 != 0) return false;
+    static const int forced = [] {  // tuning aid: DINOV2_HIP_GEMM_TILE=128|256
+        const char* e = getenv("DINOV2_HIP_GEMM_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 128) return false;
+    if (a.N % 256 != 0 || (a.K / 64) % 2 != 0) return false;  // gemm2 preconditions
+    if (forced == 256) return true;
     const long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
     return tiles >= 192;
 }
 
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    const bool big = use_big_tile(a);
-    if (dt == DT_F16)
-        return big ? launch_cfg<_Float16, 256, 256, 2, 4>(epi, a, st) : launch_cfg<_Float16, 128, 128, 2, 2>(epi, a, st);
-    return big ? launch_cfg<__bf16, 256, 256, 2, 4>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2>(epi, a, st);
+    if (epi != EPI_PATCH && use_big_tile(a)) return launch_gemm2(dt, epi, a, st);
+    return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2>(epi, a, st);
 }
 
 }  // namespace dinov2

@@ -1,0 +1,391 @@
+// gemm2.hip -- the main f16/bf16 MFMA GEMM of the forward pass (256x256x64 tile, persistent), second generation.
+//
+// Same contract and epilogues as gemm.hip (which stays as the 128x128 edge-guarded kernel for small / odd shapes).
+// Every structural choice below comes from a measurement on MI355X (profiles/r01_gemm_tuning.md):
+//   * PERSISTENT workgroups (grid = min(tiles, 256), one per CU).  Retiring and relaunching a 512-thread / 128 KiB-LDS
+//     workgroup per tile cost about as much as the whole K = 1024 loop (fixed 31 us per tile -> 15 us).
+//   * OPERAND SWAP: the weight tile is the MFMA A operand and the activation tile the B operand, so a 32x32
+//     accumulator block holds C^T: lane l owns ONE token row (l & 31) and, per 4-register group, FOUR CONSECUTIVE
+//     output columns -> vector bias / LayerScale loads and 8/16-byte LDS writes in the epilogue.
+//   * REGISTER DOUBLE-BUFFERED FRAGMENTS with HAND-COUNTED waits: the six ds_read_b128 of k-step s+1 are issued (inline
+//     asm) before the eight MFMAs of k-step s, across the K-tile boundary too, and waited for with s_waitcnt lgkmcnt(6).
+//     hipcc's own wait insertion put lgkmcnt(0) right behind freshly issued reads.
+//   * LOADS TWO K-TILES AHEAD, ONE BARRIER PER K-TILE: global_load_lds for K-tile t+2 is issued right after the barrier
+//     that publishes K-tile t+1; the NEXT output tile's first K-tile is issued after the last barrier of the current one,
+//     so its HBM/L2 latency (8k cycles when exposed) hides under the epilogue.
+//   * FULL-LINE EPILOGUE THROUGH LDS: each wave transposes its 128x64 result through a private 8 KiB slice of the idle
+//     second LDS stage and moves whole 128-byte lines (lane l owns 16 B of row 8*it + (l >> 3)); residual-stream reads are
+//     issued one pass ahead of the stores that would otherwise force a vmcnt(0) drain (gfx950 counts stores on vmcnt).
+// Fragment layouts, LDS swizzle and the XCD-aware tile order are those of gemm.hip.
+#include "device_types.h"
+#include "kernels.h"
+
+// tuning aid, compile-time only (make variant): 2 = skip in-loop staging, 4 = skip MFMA
+#ifndef DINO_GEMM_DBG
+#define DINO_GEMM_DBG 0
+#endif
+
+namespace dinov2 {
+
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
+    using E = Elem<T>;
+    using vec8 = typename E::vec8;
+    using vec4 = typename E::vec4;
+    constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
+    constexpr int ROWB = BK * 2;
+    constexpr int STAGE = (BM + BN) * ROWB;  // 64 KiB per K-tile, two stages
+    constexpr int XREP = 4, WREP = 2;        // wave tile: 128 tokens x 64 output columns
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = p.M, N = p.N, K = p.K;
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int ntiles = ntn * ntm;
+    // Block b sits on XCD b % 8 (observed placement; affects speed only): each XCD walks a contiguous chunk of the tile
+    // order, its blocks side by side, so concurrently running tiles share operand panels in that XCD's L2.
+    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+    const int nb_x = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);  // blocks of this grid on my XCD
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int chunk0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int chunkn = tq + (xcd < tr ? 1 : 0);
+
+    // ---- staging: 4 + 4 global_load_lds_dwordx4 per thread per K-tile, rows clamped to M ----
+    unsigned xsrc[4], wsrc[4];  // byte offsets from p.A / p.W (both far below 4 GiB)
+    const int srow = lane >> 3;
+    auto set_tile = [&](int m0, int n0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = (j * NW + wid) * 8 + srow;
+            const int lc = (lane & 7) ^ ((row >> 1) & 7);
+            int gm = m0 + row;
+            gm = gm < M ? gm : M - 1;
+            xsrc[j] = (unsigned)gm * (unsigned)(K * 2) + lc * 16;
+            wsrc[j] = (unsigned)(n0 + row) * (unsigned)(K * 2) + lc * 16;
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* sX = smem + buf * STAGE;
+        char* sW = sX + BM * ROWB;
+        const char* ga = (const char*)p.A + (size_t)kt * (BK * 2);
+        const char* gw = (const char*)p.W + (size_t)kt * (BK * 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(ga + xsrc[j], sX + (j * NW + wid) * 8 * ROWB);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) glds16(gw + wsrc[j], sW + (j * NW + wid) * 8 * ROWB);
+    };
+
+    const int wx = wid >> 2, ww = wid & 3;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int sw = (fr >> 1) & 7;
+    const int xoff = (wx * 128 + fr) * ROWB;
+    const int woff = (ww * 64 + fr) * ROWB;  // + BM*ROWB = 32768 goes into the instruction offset
+
+    const unsigned lds0 = (unsigned)(uintptr_t)(DINO_LDS_AS char*)smem;
+    unsigned xaddr[4], waddr[4];  // per k-step LDS byte address of this lane's first X / W fragment row (stage 0)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const unsigned ch = (unsigned)(((ks * 2 + fh) ^ sw) << 4);
+        xaddr[ks] = lds0 + (unsigned)xoff + ch;
+        waddr[ks] = lds0 + (unsigned)woff + ch;
+    }
+
+#if DINO_GEMM_DBG & 8  // tuning aid: block 0 / thread 0 stamps s_memtime at phase boundaries of its first tiles
+    int tsn = 0;
+#define DINO_TS() \
+    if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 64) p.ts[tsn++] = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define DINO_TS()
+#endif
+
+    const int nk = K / BK;  // even (checked by the launcher): the last K-tile sits in stage 1, stage 0 is free for the
+                            // next tile's first K-tile while the epilogue works in stage 1
+    if (bidx < chunkn) {
+        const int lid = chunk0 + bidx;
+        set_tile((lid / ntn) * BM, (lid % ntn) * BN);
+        stage(0, 0);
+    }
+    for (int tix = bidx; tix < chunkn; tix += nb_x) {
+        DINO_TS();
+        const int lid = chunk0 + tix;
+        const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+
+        f32x16 acc[WREP][XREP];
+#pragma unroll
+        for (int j = 0; j < WREP; ++j)
+#pragma unroll
+            for (int i = 0; i < XREP; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+
+        u32x4 xf0[XREP], wf0[WREP], xf1[XREP], wf1[WREP];
+
+        // ---- main loop ---------------------------------------------------------------------------------------------
+        // Rules followed for the inline-asm reads (cdna_hip_programming.md 5.7): every asm read is waited for by an asm
+        // s_waitcnt before its first consumer, and a sched_barrier(0) follows each wait so no MFMA is hoisted above it.
+#define DINO_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define DINO_LOAD_FRAGS(XF, WF, BUFOFF, KS)                                      \
+    {                                                                            \
+        const unsigned xa__ = xaddr[KS] + (BUFOFF), wa__ = waddr[KS] + (BUFOFF); \
+        DINO_DSR(XF[0], xa__, 0);                                                \
+        DINO_DSR(XF[1], xa__, 4096);                                             \
+        DINO_DSR(XF[2], xa__, 8192);                                             \
+        DINO_DSR(XF[3], xa__, 12288);                                            \
+        DINO_DSR(WF[0], wa__, 32768);                                            \
+        DINO_DSR(WF[1], wa__, 36864);                                            \
+    }
+#define DINO_WAIT_LGKM(N)                                   \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+#define DINO_MFMAS(XF, WF)                                                                                            \
+    {                                                                                                                 \
+        if constexpr ((DINO_GEMM_DBG & 4) == 0) {                                                                     \
+            _Pragma("unroll") for (int i = 0; i < XREP; ++i) _Pragma("unroll") for (int j = 0; j < WREP; ++j)         \
+                acc[j][i] = E::mfma32(__builtin_bit_cast(vec8, WF[j]), __builtin_bit_cast(vec8, XF[i]), acc[j][i]);   \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < XREP; ++i) _Pragma("unroll") for (int j = 0; j < WREP; ++j)         \
+                acc[j][i][0] += (float)WF[j][0] * (float)XF[i][0];                                                    \
+        }                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+    }
+
+        __syncthreads();  // K-tile 0 of this tile has landed (vmcnt(0) precedes the barrier; also drains the previous
+                          // tile's stores) and every wave has left the previous tile's epilogue slices in stage 1
+        DINO_TS();
+        if (!(DINO_GEMM_DBG & 2)) stage(1, 1);
+        DINO_LOAD_FRAGS(xf0, wf0, 0u, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = (unsigned)((kt + 1) & 1) * STAGE;
+            DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
+            DINO_WAIT_LGKM(6);                  // the older six (k-step 0) have returned
+            DINO_MFMAS(xf0, wf0);
+            DINO_LOAD_FRAGS(xf0, wf0, cur, 2);
+            DINO_WAIT_LGKM(6);
+            DINO_MFMAS(xf1, wf1);
+            DINO_LOAD_FRAGS(xf1, wf1, cur, 3);
+            DINO_WAIT_LGKM(6);
+            DINO_MFMAS(xf0, wf0);
+            // k-step-3 fragments (issued one MFMA group ago) must be in registers before the barrier: after it nobody
+            // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
+            // of K-tile kt+1 (issued a whole K-tile ago) has landed; after the barrier everyone's has.
+            DINO_WAIT_LGKM(0);
+            __syncthreads();
+            if (kt + 2 < nk) {
+                if (!(DINO_GEMM_DBG & 2)) stage(kt & 1, kt + 2);
+            } else if (kt + 1 == nk && tix + nb_x < chunkn) {
+                // last K-tile of this output tile: stage 0 is idle -> start the NEXT tile's first K-tile now
+                const int nl = chunk0 + tix + nb_x;
+                set_tile((nl / ntn) * BM, (nl % ntn) * BN);
+                stage(0, 0);
+            }
+            DINO_LOAD_FRAGS(xf0, wf0, nxt, 0);  // after the last K-tile this reads LDS that is never used
+            __builtin_amdgcn_sched_barrier(0);
+            DINO_MFMAS(xf1, wf1);
+        }
+        DINO_WAIT_LGKM(0);
+        DINO_TS();
+#undef DINO_DSR
+#undef DINO_LOAD_FRAGS
+#undef DINO_WAIT_LGKM
+#undef DINO_MFMAS
+
+        // ---- epilogue ----------------------------------------------------------------------------------------------
+        // acc[j][i][4g + e] = C[m, n] with  m = m0 + wx*128 + i*32 + (lane & 31)
+        //                                   n = n0 + ww*64 + j*32 + 8g + 4*(lane >> 5) + e
+        // LDS slice image: 64 rows x 128 B, 16-byte slot s of row r stored at slot s ^ (r & 7) (conflict-free reads).
+        // No block barrier is needed before writing the slices: they lie in stage 1, which nobody reads after the last
+        // K-tile barrier (all k-step-3 fragments were in registers before it).
+        // `el` launders the lane id: without it LICM hoists ~40 loop-invariant epilogue addresses out of the persistent
+        // tile loop, they stay live across the K loop and the kernel spills (fatal next to the asm-loaded fragments).
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int er = el & 31, eh = el >> 5;
+        char* const ep = smem + STAGE + wid * 8192;
+        const int mbase = m0 + wx * 128;
+        const int ncol = n0 + ww * 64 + 4 * eh;
+
+        float4 bs[WREP][4];
+#pragma unroll
+        for (int j = 0; j < WREP; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                bs[j][g] = p.bias ? *(const float4*)(p.bias + ncol + j * 32 + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+        if constexpr (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_SWIGLU) {
+            // 2-byte outputs: two passes of 64 rows x 64 columns (SwiGLU: x 32)
+            const float qs = (EPI == EPI_QKV && n0 < p.qcols) ? p.qscale : 1.0f;  // tiles never straddle q|k|v
+            constexpr int JN = EPI == EPI_SWIGLU ? 1 : WREP;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                for (int j = 0; j < JN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float bb[4] = {bs[j][g].x, bs[j][g].y, bs[j][g].z, bs[j][g].w};
+                        const float b2[4] = {bs[1][g].x, bs[1][g].y, bs[1][g].z, bs[1][g].w};
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            const int i = 2 * q + ii;
+                            vec4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float v = acc[j][i][4 * g + e] + bb[e];
+                                if constexpr (EPI == EPI_QKV) {
+                                    o[e] = E::from_f32(v * qs);
+                                } else if constexpr (EPI == EPI_SWIGLU) {
+                                    // W rows interleaved in 32-blocks: j = 0 holds x1[32q..], j = 1 holds x2[32q..]
+                                    const float h2 = acc[1][i][4 * g + e] + b2[e];
+                                    o[e] = E::from_f32(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2);  // silu(x1) * x2
+                                } else {
+                                    // EPI_GELU, ggml semantics: y = table[f16(x)], table[h] = f16(gelu_tanh(f32(h))).
+                                    // 0.5 x (1 + tanh u) == x / (1 + exp(-2u)); the reference's x <= -10 -> 0 and
+                                    // x >= 10 -> x branches fall out of the formula after the f16 roundings (exp -> inf
+                                    // gives -0, exp -> 0 gives x), so no compares are needed.
+                                    const float xr = (float)(_Float16)v;
+                                    const float t = xr * (-2.302208199f - 0.1029432397f * xr * xr);  // -2 log2(e) u
+                                    const float gl = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+                                    o[e] = E::from_f32((float)(_Float16)gl);
+                                }
+                            }
+                            const int row = ii * 32 + er;
+                            const int slot = (4 * j + g) ^ (row & 7);
+                            *(vec4*)(ep + row * 128 + slot * 16 + eh * 8) = o;
+                        }
+                    }
+                __builtin_amdgcn_wave_barrier();
+                if constexpr (EPI == EPI_SWIGLU) {
+                    const int hid0 = ((n0 + ww * 64) >> 6) * 32;  // 32 hidden units = 64 B per row: 4 lanes per row
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int row = it * 16 + (el >> 2), slot = el & 3;
+                        const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                        const int m = mbase + q * 64 + row;
+                        if (m < M) *(u32x4*)((T*)p.out + (size_t)m * p.ldo + hid0 + slot * 8) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        const int row = it * 8 + (el >> 3), slot = el & 7;
+                        const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                        const int m = mbase + q * 64 + row;
+                        if (m < M) *(u32x4*)((T*)p.out + (size_t)m * p.ldo + n0 + ww * 64 + slot * 8) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
+            // 4-byte outputs: four passes of 64 rows x 32 columns (128 B per row).  All loads of a pass (residual stream /
+            // pos-embed rows) are issued before its LDS transposition and long before its first store.
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int j = ps >> 1, q = ps & 1;
+                const int nb = n0 + ww * 64 + j * 32 + (el & 7) * 4;
+                float4 add[8];
+                if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        int m = mbase + q * 64 + it * 8 + (el >> 3);
+                        m = m < M ? m : M - 1;
+                        if constexpr (EPI == EPI_PATCH) {
+                            const int pp = m % p.P;
+                            add[it] = *(const float4*)(p.aux + (size_t)(1 + pp) * N + nb);
+                        } else {
+                            add[it] = *(const float4*)((const float*)p.out + (size_t)m * p.ldo + nb);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 ls = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if constexpr (EPI == EPI_RESID) ls = *(const float4*)(p.aux + ncol + j * 32 + 8 * g);
+                    const float4 b4 = bs[j][g];
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii) {
+                        const int i = 2 * q + ii;
+                        const int row = ii * 32 + er;
+                        const int slot = (2 * g + eh) ^ (row & 7);
+                        *(float4*)(ep + row * 128 + slot * 16) =
+                            make_float4((acc[j][i][4 * g + 0] + b4.x) * ls.x, (acc[j][i][4 * g + 1] + b4.y) * ls.y,
+                                        (acc[j][i][4 * g + 2] + b4.z) * ls.z, (acc[j][i][4 * g + 3] + b4.w) * ls.w);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 8 + (el >> 3), slot = el & 7;
+                    float4 v = *(const float4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                    if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH)
+                        v = make_float4(v.x + add[it].x, v.y + add[it].y, v.z + add[it].z, v.w + add[it].w);
+                    const int m = mbase + q * 64 + row;
+                    if (m < M) {
+                        size_t o;
+                        if constexpr (EPI == EPI_PATCH) {
+                            const int b = m / p.P, pp = m - b * p.P;
+                            o = ((size_t)b * p.T + 1 + p.R + pp) * p.ldo + nb;
+                        } else {
+                            o = (size_t)m * p.ldo + nb;
+                        }
+                        *(float4*)((float*)p.out + o) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        DINO_TS();
+    }  // persistent tile loop
+#undef DINO_TS
+}
+
+template <typename T>
+static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    const int tiles = (a.N / 256) * ((a.M + 255) / 256);
+    const dim3 grid(tiles < 256 ? tiles : 256), block(512);
+    const size_t lds = 2 * 512 * 128;
+#define DINO_L2(E)                                                         \
+    case E:                                                                \
+        hipLaunchKernelGGL((gemm2_kernel<T, E>), grid, block, lds, st, a); \
+        break;
+    switch (epi) {
+        case EPI_PATCH: return hipErrorInvalidValue;  // patch-embed (0.16 % of FLOPs) stays on the 128x128 kernel
+        DINO_L2(EPI_QKV)
+        DINO_L2(EPI_RESID)
+        DINO_L2(EPI_GELU)
+        DINO_L2(EPI_SWIGLU)
+        DINO_L2(EPI_PLAIN_F32)
+    }
+#undef DINO_L2
+    return hipGetLastError();
+}
+
+// requires N % 256 == 0 and (K / 64) even
+hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    return dt == DT_F16 ? launch2_t<_Float16>(epi, a, st) : launch2_t<__bf16>(epi, a, st);
+}
+
+template <typename T>
+static hipError_t attr2_t() {
+    hipError_t e = hipSuccess;
+    const int lds = 2 * 512 * 128;
+#define DINO_A2(E)                                                                  \
+    if (e == hipSuccess)                                                            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<T, E>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DINO_A2(EPI_QKV)
+    DINO_A2(EPI_RESID)
+    DINO_A2(EPI_GELU)
+    DINO_A2(EPI_SWIGLU)
+    DINO_A2(EPI_PLAIN_F32)
+#undef DINO_A2
+    return e;
+}
+
+hipError_t gemm2_init() {
+    hipError_t e = attr2_t<_Float16>();
+    if (e == hipSuccess) e = attr2_t<__bf16>();
+    return e;
+}
+
+}  // namespace dinov2

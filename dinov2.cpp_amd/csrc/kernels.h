@@ -30,6 +30,7 @@ struct GemmArgs {
     int P, T, R;        // EPI_PATCH token mapping
     int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale
     float qscale;
+    long long* ts;      // tuning aid: if non-null, block 0 / wave 0 writes s_memtime stamps of its first tiles here
 };
 
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);

@@ -2,6 +2,9 @@
 // tests can check each hand-written kernel against the oracle / numpy in isolation.  Not used by predict.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -153,4 +156,94 @@ extern "C" int dinov2_hip_op_probe_tr16(int16_t* out256) {
     OP_TRY(hipDeviceSynchronize());
     OP_TRY(hipMemcpy(out256, d.p, 512, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// ---- micro-benchmarks: device-resident random operands, HIP-event timing around `iters` launches ----
+namespace {
+void fill_random_t(DType dt, void* dev, size_t n, unsigned seed, float scale) {
+    std::vector<uint16_t> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        const float v = (((float)(s >> 8) / 8388608.0f) - 1.0f) * scale;  // uniform [-scale, scale): full-range random
+        if (dt == DT_F16) {
+            _Float16 x = (_Float16)v;
+            std::memcpy(&h[i], &x, 2);
+        } else {
+            uint32_t u;
+            std::memcpy(&u, &v, 4);
+            h[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+    }
+    (void)hipMemcpy(dev, h.data(), n * 2, hipMemcpyHostToDevice);
+}
+}  // namespace
+
+extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    if (gemm_init() != hipSuccess) return -1.f;
+    DevBuf dA, dW, dB, dX, dO;
+    if (dA.alloc((size_t)M * K * 2) != hipSuccess || dW.alloc((size_t)N * K * 2) != hipSuccess ||
+        dB.alloc((size_t)N * 4) != hipSuccess || dX.alloc((size_t)std::max(N, 4096) * 4 * 2) != hipSuccess ||
+        dO.alloc((size_t)M * N * 4) != hipSuccess)
+        return -1.f;
+    fill_random_t(dt, dA.p, (size_t)M * K, 1, 1.0f);
+    fill_random_t(dt, dW.p, (size_t)N * K, 2, 0.05f);
+    (void)hipMemset(dB.p, 0, (size_t)N * 4);
+    (void)hipMemset(dX.p, 0, (size_t)std::max(N, 4096) * 8);
+    (void)hipMemset(dO.p, 0, (size_t)M * N * 4);
+    GemmArgs a{};
+    a.A = dA.p; a.W = dW.p; a.bias = (const float*)dB.p; a.out = dO.p; a.aux = (const float*)dX.p;
+    a.M = M; a.N = N; a.K = K; a.ldo = epilogue == EPI_SWIGLU ? N / 2 : N; a.P = 1; a.T = 2; a.R = 0;
+    a.qcols = N / 3; a.qscale = 0.125f;
+    if (epilogue == EPI_PATCH) { a.P = M; a.T = M + 1; }
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);
+    if (getenv("DINOV2_HIP_GEMM_TS")) {  // tuning aid: print s_memtime phase stamps of block 0 / wave 0
+        DevBuf dT;
+        if (dT.alloc(64 * 8) == hipSuccess) {
+            (void)hipMemset(dT.p, 0, 64 * 8);
+            a.ts = (long long*)dT.p;
+            (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);
+            (void)hipDeviceSynchronize();
+            long long h[64];
+            (void)hipMemcpy(h, dT.p, sizeof h, hipMemcpyDeviceToHost);
+            printf("ts deltas:");
+            for (int i = 1; i < 64 && h[i]; ++i) printf(" %lld", h[i] - h[i - 1]);
+            printf("\n");
+            a.ts = nullptr;
+        }
+    }
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms / iters;
+}
+
+extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t nh, int32_t iters) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    DevBuf dQ, dO;
+    const size_t nq = (size_t)B * T * 3 * H, no = (size_t)B * T * H;
+    if (dQ.alloc(nq * 2) != hipSuccess || dO.alloc(no * 2) != hipSuccess) return -1.f;
+    fill_random_t(dt, dQ.p, nq, 3, 1.0f);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, nullptr);
+    (void)hipEventRecord(e0, nullptr);
+    for (int i = 0; i < iters; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms / iters;
 }

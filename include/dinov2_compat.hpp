@@ -1,0 +1,200 @@
+// dinov2_compat.hpp -- header-only C++ shim with the reference's host API shape, on top of the C-ABI.
+//
+// The reference's own header (/root/reference/dinov2.h) cannot be reused verbatim: it includes ggml and OpenCV
+// headers, declares `constexpr std::string PATTERN` at namespace scope (dinov2.h:18, ill-formed before C++20
+// library support) and its `attn` declaration does not match the definition (dinov2.h:70 vs dinov2.cpp:458).
+// This shim keeps the names, argument order and error behaviour of the two entry points callers use
+// (inference.cpp:45,65; realtime.cpp:45,70) so that swapping the include and the link line is the whole port:
+//
+//   reference                                                    here
+//   -----------------------------------------------------------  ------------------------------------------------
+//   struct dino_params            dinov2.h:57-68                  struct dino_params   (same fields/defaults)
+//   struct dino_hparams           dinov2.h:25-47                  struct dino_hparams
+//   struct dino_model             dinov2.h:49-55                  struct dino_model    (owns the C-ABI handles)
+//   struct dino_output            dinov2.h:85-88                  struct dino_output   (Mat32f instead of cv::Mat)
+//   bool dino_model_load(cv::Size, const std::string&,            bool dino_model_load(Size2i, const std::string&,
+//        dino_model&, const dino_params&)     dinov2.h:98-99           dino_model&, const dino_params&)
+//   std::unique_ptr<dino_output> dino_predict(const dino_model&,  std::unique_ptr<dino_output> dino_predict(
+//        const cv::Mat&, const dino_params&, ggml_gallocr_t)           const dino_model&, const Mat32f&,
+//                                             dinov2.h:111-112         const dino_params&, dinov2_hip_session*)
+//
+// `Mat32f` is layout-compatible with a continuous CV_32FC3 cv::Mat; define DINOV2_WITH_OPENCV before including to
+// get cv::Mat / cv::Size overloads.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <memory>
+#include <optional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "dinov2_hip.h"
+
+#ifdef DINOV2_WITH_OPENCV
+#include <opencv2/core/mat.hpp>
+#endif
+
+struct Size2i {
+    int width = 0, height = 0;
+};
+
+// Row-major H x W x C float image / matrix view (step in bytes), as cv::Mat(rows, cols, CV_32FC(channels)).
+struct Mat32f {
+    int rows = 0, cols = 0, channels = 1;
+    float* data = nullptr;
+    size_t step = 0;                      // bytes per row; 0 = continuous
+    std::shared_ptr<std::vector<float>> owner;  // set when the Mat owns its memory (dino_output::patch_tokens)
+    Size2i size() const { return Size2i{cols, rows}; }
+    bool isContinuous() const { return step == 0 || step == sizeof(float) * (size_t)cols * channels; }
+};
+
+struct dino_hparams {  // dinov2.h:25-47
+    uint32_t hidden_size = 768, num_hidden_layers = 12, num_attention_heads = 12, num_classes = 1000;
+    uint32_t num_register_tokens = 0, patch_size = 8, img_size = 224, ftype = 1;
+    float eps = 1e-6f;
+    std::string interpolation = "bicubic";
+    std::map<int, std::string> id2label;
+    uint32_t n_enc_head_dim() const { return hidden_size / num_attention_heads; }
+    uint32_t n_img_size() const { return img_size; }
+    uint32_t n_patch_size() const { return patch_size; }
+    uint32_t n_img_embd() const { return img_size / patch_size; }
+};
+
+struct dino_params {  // dinov2.h:57-68
+    uint32_t seed = 42;
+    uint32_t topk = 5;
+    bool enable_flash_attn = false;  // accepted, ignored: attention is always the fused, exactly-masked kernel
+    uint8_t camera_id = 0;
+    uint32_t n_threads = std::min(4u, std::thread::hardware_concurrency());  // unused on the GPU path
+    bool classify = false;
+    std::string model = "../ggml-model-f16.gguf";
+    std::string fname_inp = "../assets/tench.jpg";
+    std::string image_out = "pca_visual.jpg";
+    float eps = 1e-6f;
+    int device = 0;                       // extension: HIP device ordinal
+    int compute_dtype = DINOV2_HIP_F16;   // extension: DINOV2_HIP_F16 | DINOV2_HIP_BF16
+};
+
+struct dino_model {  // dinov2.h:49-55 (ctx/backend/buffer/tensors collapse into one opaque handle)
+    dino_hparams hparams;
+    dinov2_hip_model* handle = nullptr;
+    dinov2_hip_session* default_session = nullptr;
+    dino_model() = default;
+    dino_model(const dino_model&) = delete;
+    dino_model& operator=(const dino_model&) = delete;
+    ~dino_model() {
+        if (default_session) dinov2_hip_session_free(default_session);
+        if (handle) dinov2_hip_model_free(handle);
+    }
+};
+
+struct dino_output {  // dinov2.h:85-88
+    std::optional<std::vector<uint32_t>> preds;  // top-k class ids (the reference stores uint32(prob): dinov2.cpp:975)
+    std::optional<std::vector<float>> probs;     // their probabilities (extension)
+    std::optional<Mat32f> patch_tokens;          // P x H, row = y*w0 + x (dinov2.cpp:979-992)
+};
+
+// dinov2.h:98-99 / dinov2.cpp:239-352.  img_size is unused, exactly as in the reference.
+inline bool dino_model_load(Size2i /*img_size*/, const std::string& fname, dino_model& model, const dino_params& params) {
+    printf("%s: loading model from '%s' - please wait\n", __func__, fname.c_str());
+    dinov2_hip_load_opts o;
+    dinov2_hip_default_load_opts(&o);
+    o.device = params.device;
+    o.compute_dtype = params.compute_dtype;
+    o.classify = params.classify ? 1 : 0;
+    char err[512] = {0};
+    if (dinov2_hip_model_load(fname.c_str(), &o, &model.handle, err, sizeof err) != DINOV2_HIP_OK) {
+        fprintf(stderr, "%s: %s\n", __func__, err);  // reference: "failed to open" + return false (dinov2.cpp:269-272)
+        return false;
+    }
+    dinov2_hip_hparams hp;
+    dinov2_hip_model_hparams(model.handle, &hp);
+    auto& h = model.hparams;
+    h.hidden_size = hp.hidden_size; h.num_hidden_layers = hp.num_hidden_layers;
+    h.num_attention_heads = hp.num_attention_heads; h.num_classes = hp.num_classes;
+    h.num_register_tokens = hp.num_register_tokens; h.patch_size = hp.patch_size; h.img_size = hp.img_size;
+    h.ftype = hp.ftype; h.eps = hp.eps;
+    // same echo as dinov2.cpp:288-299
+    printf("%s: hidden_size            = %u\n", __func__, h.hidden_size);
+    printf("%s: num_hidden_layers      = %u\n", __func__, h.num_hidden_layers);
+    printf("%s: num_register_tokens    = %u\n", __func__, h.num_register_tokens);
+    printf("%s: num_attention_heads    = %u\n", __func__, h.num_attention_heads);
+    printf("%s: patch_size             = %u\n", __func__, h.patch_size);
+    printf("%s: img_size               = %u\n", __func__, h.img_size);
+    printf("%s: ftype                  = %u\n", __func__, h.ftype);
+    if (params.classify && hp.has_classifier) {
+        printf("%s: num_classes            = %u\n", __func__, h.num_classes);
+        for (uint32_t i = 0; i < h.num_classes; ++i) {
+            const char* s = dinov2_hip_model_label(model.handle, (int32_t)i);
+            h.id2label[(int)i] = s ? s : "";
+        }
+    }
+    if (dinov2_hip_session_create(model.handle, nullptr, &model.default_session, err, sizeof err) != DINOV2_HIP_OK) {
+        fprintf(stderr, "%s: %s\n", __func__, err);
+        return false;
+    }
+    return true;
+}
+
+// dinov2.h:111-112 / dinov2.cpp:900-999.  `img`: preprocessed CV_32FC3-compatible BGR-interleaved image whose size is a
+// multiple of patch_size; `allocr`: a reusable session (nullptr = the model's default one).  Returns {} on failure.
+inline std::unique_ptr<dino_output> dino_predict(const dino_model& model, const Mat32f& img, const dino_params& params,
+                                                 dinov2_hip_session* allocr = nullptr) {
+    dinov2_hip_session* s = allocr ? allocr : model.default_session;
+    if (!s || !img.data || img.channels != 3 || !img.isContinuous()) {
+        fprintf(stderr, "%s: need a continuous 3-channel float image\n", __func__);
+        return {};
+    }
+    dinov2_hip_input in{img.data, 1, img.rows, img.cols, DINOV2_HIP_BGR_HWC, 0};
+    dinov2_hip_output out{};
+    auto output = std::make_unique<dino_output>();
+    char err[512] = {0};
+    if (params.classify) {
+        std::vector<int32_t> ids(params.topk);
+        std::vector<float> pr(params.topk);
+        out.topk_ids = ids.data(); out.topk_probs = pr.data(); out.topk = (int32_t)params.topk;
+        if (dinov2_hip_predict(s, &in, &out, DINOV2_HIP_CLASSIFY, err, sizeof err) != DINOV2_HIP_OK) {
+            fprintf(stderr, "%s: %s\n", __func__, err);
+            return {};
+        }
+        fprintf(stderr, "\n");
+        std::vector<uint32_t> preds;
+        for (uint32_t i = 0; i < params.topk && ids[i] >= 0; ++i) {  // same lines as dinov2.cpp:972-974
+            auto it = model.hparams.id2label.find(ids[i]);
+            printf(" > %s : %.2f\n", it == model.hparams.id2label.end() ? "?" : it->second.c_str(), pr[i]);
+            preds.push_back((uint32_t)ids[i]);
+        }
+        output->preds = preds;
+        output->probs = pr;
+    } else {
+        const int ps = (int)model.hparams.patch_size;
+        const int P = (img.rows / ps) * (img.cols / ps), H = (int)model.hparams.hidden_size;
+        Mat32f m;
+        m.rows = P; m.cols = H; m.channels = 1;
+        m.owner = std::make_shared<std::vector<float>>((size_t)P * H);
+        m.data = m.owner->data();
+        out.patch_tokens = m.data;
+        if (dinov2_hip_predict(s, &in, &out, 0, err, sizeof err) != DINOV2_HIP_OK) {
+            fprintf(stderr, "%s: %s\n", __func__, err);
+            return {};
+        }
+        output->patch_tokens = m;
+    }
+    return output;
+}
+
+#ifdef DINOV2_WITH_OPENCV
+inline bool dino_model_load(cv::Size sz, const std::string& fname, dino_model& model, const dino_params& params) {
+    return dino_model_load(Size2i{sz.width, sz.height}, fname, model, params);
+}
+inline std::unique_ptr<dino_output> dino_predict(const dino_model& model, const cv::Mat& img, const dino_params& params,
+                                                 dinov2_hip_session* allocr = nullptr) {
+    cv::Mat c = img.isContinuous() ? img : img.clone();
+    Mat32f v;
+    v.rows = c.rows; v.cols = c.cols; v.channels = c.channels(); v.data = (float*)c.data;
+    return dino_predict(model, v, params, allocr);
+}
+#endif

@@ -36,6 +36,11 @@ int dinov2_hip_op_convert_weight(int32_t dtype, const void *src, uint64_t src_by
 /* what ds_read_b64_tr_b16 hands each lane for addr = lane*8 over an LDS image of its own indices: out[64][4] */
 int dinov2_hip_op_probe_tr16(int16_t *out256);
 
+/* micro-benchmarks on device-resident uniform-random operands: average ms per launch over `iters` launches (HIP events),
+ * negative on error.  Used by tools/kernel_bench.py to price one kernel against its roofline. */
+float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters);
+float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t nh, int32_t iters);
+
 #ifdef __cplusplus
 }
 #endif

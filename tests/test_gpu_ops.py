@@ -220,3 +220,43 @@ def test_convert_weight_dequant(api, pkg, tname):
     assert api.lib().dinov2_hip_op_convert_weight(F16, C.cast(buf, C.c_void_p), len(raw), gt, _p(out), N, K, Kpad, 0) == 0
     assert np.array_equal(out[:, :K], ref.astype(np.float16).astype(np.float32))
     assert not out[:, K:].any()
+
+
+@pytest.mark.parametrize("epi", ["plain", "resid", "qkv", "gelu"])
+@pytest.mark.parametrize("M,N,K", [(20000, 1024, 512), (43968, 1024, 1024), (9000, 3072, 256)])
+def test_gemm_persistent_multi_tile(api, epi, M, N, K):
+    """The 256x256 persistent kernel with more tiles than CUs: every block walks several tiles, prefetching the next
+    tile's first K-tile under its epilogue.  Whole output checked (a stale-LDS race shows up as a few wrong tiles)."""
+    rng = np.random.default_rng(M + K)
+    A = _round(rng.standard_normal((M, K)), F16)
+    W = _round(rng.standard_normal((N, K)) * 0.05 + np.linspace(-0.02, 0.03, N)[:, None], F16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A @ W.T + bias  # f32 sgemm: same rounding contract, different summation order
+    if epi == "plain":
+        out = np.full((M, N), np.nan, np.float32)
+        _gemm(api, F16, EPI_PLAIN, A, W, bias, None, out, M, N, K, N)
+        tol = 2e-4
+    elif epi == "resid":
+        ls = rng.standard_normal(N).astype(np.float32)
+        x0 = rng.standard_normal((M, N)).astype(np.float32)
+        out = x0.copy()
+        _gemm(api, F16, EPI_RESID, A, W, bias, ls, out, M, N, K, N)
+        ref = x0 + ls * ref
+        tol = 5e-4
+    elif epi == "qkv":
+        out = np.zeros((M, N), np.float32)
+        _gemm(api, F16, EPI_QKV, A, W, bias, None, out, M, N, K, N, qcols=N // 4 * 2 if N % 512 == 0 else 256, qscale=0.125)
+        qc = N // 4 * 2 if N % 512 == 0 else 256
+        ref[:, :qc] *= 0.125
+        ref = _round(ref, F16)
+        tol = 2e-3
+    else:
+        out = np.zeros((M, N), np.float32)
+        _gemm(api, F16, EPI_GELU, A, W, bias, None, out, M, N, K, N)
+        xr = ref.astype(np.float16).astype(np.float64)
+        g = 0.5 * xr * (1 + np.tanh(0.79788456080286535587989211986876 * xr * (1 + 0.044715 * xr * xr)))
+        ref = g.astype(np.float32).astype(np.float16).astype(np.float32)
+        tol = 2e-3
+    assert np.isfinite(out).all()
+    bad = np.abs(out - ref) > tol * np.maximum(1.0, np.abs(ref))
+    assert bad.mean() < (1e-4 if epi == "gelu" else 1e-7), f"{bad.sum()} mismatches, first at {np.argwhere(bad)[:4]}"
