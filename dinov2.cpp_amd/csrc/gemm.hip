@@ -30,6 +30,7 @@ namespace dinov2 {
 
 template <typename T, int BM, int BN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+#pragma clang fp contract(off)  // position-independent results: see gemm2.hip
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     constexpr int NW = WM * WN;
@@ -145,8 +146,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                 const int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
                 if (row < M && c2 < N) {
                     const float h1 = acc[i][0][r] + b1, h2 = acc[i][1][r] + b2;
-                    const float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1));  // silu, dinov2.cpp:605
-                    out[(size_t)row * p.ldo + j] = E::from_f32(sl * h2);
+                    float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1)) * h2;  // silu(x1) * x2, dinov2.cpp:605
+                    asm volatile("" : "+v"(sl));
+                    out[(size_t)row * p.ldo + j] = E::from_f32(sl);
                 }
             }
         return;
@@ -175,13 +177,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
                     if (row >= M) continue;
-                    const float v = acc[i][jn][r] + bias;
+                    float v = acc[i][jn][r] + bias;
+                    asm volatile("" : "+v"(v));  // f32 value first, then any f16 rounding (no v_fma_mix fusion: gemm2.hip)
                     if constexpr (EPI == EPI_PATCH) {
                         const int b = row / p.P, pp = row - b * p.P;
                         float* x = (float*)p.out;
                         x[((size_t)b * p.T + 1 + p.R + pp) * p.ldo + col] = v + p.aux[(size_t)(1 + pp) * N + col];
                     } else if constexpr (EPI == EPI_QKV) {
-                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(v * auxv);
+                        float vq = v * auxv;
+                        asm volatile("" : "+v"(vq));
+                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(vq);
                     } else if constexpr (EPI == EPI_RESID) {
                         ((float*)p.out)[(size_t)row * p.ldo + col] = v * auxv + xin[r];
                     } else if constexpr (EPI == EPI_GELU) {
@@ -189,6 +194,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                         const float xr = (float)(_Float16)v;
                         const float u = 0.79788456080286535587989211986876f * xr * (1.0f + 0.044715f * xr * xr);
                         float g = xr * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));  // == 0.5 x (1 + tanh u)
+                        asm volatile("" : "+v"(g));
                         g = (float)(_Float16)g;
                         g = v <= -10.0f ? 0.0f : (v >= 10.0f ? v : g);
                         ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(g);

@@ -29,6 +29,10 @@ namespace dinov2 {
 
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
+    // No implicit mul+add -> fma contraction anywhere in this kernel: the unrolled epilogue instances would otherwise be
+    // contracted differently, making an output element's last f32 bit (and, after the f16 rounding, occasionally its
+    // value) depend on WHERE its row sits in the tile.  B images must equal B independent forwards bit for bit.
+#pragma clang fp contract(off)
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
@@ -232,21 +236,31 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                             vec4 o;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float v = acc[j][i][4 * g + e] + bb[e];
+                                float v = acc[j][i][4 * g + e] + bb[e];
+                                // keep the f32 sum a real register value: hipcc otherwise fuses "add, then round to f16"
+                                // into v_fma_mixlo_f16 for SOME unrolled instances (single rounding instead of the
+                                // reference's f32-then-f16 double rounding), which made results depend on the row's
+                                // position in the tile
+                                asm volatile("" : "+v"(v));
                                 if constexpr (EPI == EPI_QKV) {
-                                    o[e] = E::from_f32(v * qs);
+                                    float vq = v * qs;
+                                    asm volatile("" : "+v"(vq));
+                                    o[e] = E::from_f32(vq);
                                 } else if constexpr (EPI == EPI_SWIGLU) {
                                     // W rows interleaved in 32-blocks: j = 0 holds x1[32q..], j = 1 holds x2[32q..]
                                     const float h2 = acc[1][i][4 * g + e] + b2[e];
-                                    o[e] = E::from_f32(v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2);  // silu(x1) * x2
+                                    float sg = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2;  // silu(x1) * x2
+                                    asm volatile("" : "+v"(sg));
+                                    o[e] = E::from_f32(sg);
                                 } else {
                                     // EPI_GELU, ggml semantics: y = table[f16(x)], table[h] = f16(gelu_tanh(f32(h))).
                                     // 0.5 x (1 + tanh u) == x / (1 + exp(-2u)); the reference's x <= -10 -> 0 and
                                     // x >= 10 -> x branches fall out of the formula after the f16 roundings (exp -> inf
                                     // gives -0, exp -> 0 gives x), so no compares are needed.
                                     const float xr = (float)(_Float16)v;
-                                    const float t = xr * (-2.302208199f - 0.1029432397f * xr * xr);  // -2 log2(e) u
-                                    const float gl = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+                                    const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
+                                    float gl = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+                                    asm volatile("" : "+v"(gl));
                                     o[e] = E::from_f32((float)(_Float16)gl);
                                 }
                             }

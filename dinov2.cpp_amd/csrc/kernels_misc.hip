@@ -52,8 +52,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int i = lane + 64 * j;
         if (i < nv) {
             const float4 ww = ((const float4*)w)[i], bb = ((const float4*)bta)[i];
-            const float r0 = v[j].x * scale * ww.x + bb.x, r1 = v[j].y * scale * ww.y + bb.y;
-            const float r2 = v[j].z * scale * ww.z + bb.z, r3 = v[j].w * scale * ww.w + bb.w;
+            float r0 = v[j].x * scale * ww.x + bb.x, r1 = v[j].y * scale * ww.y + bb.y;
+            float r2 = v[j].z * scale * ww.z + bb.z, r3 = v[j].w * scale * ww.w + bb.w;
+            // f32 result first, f16 rounding second (ggml rounds at the NEXT mul_mat): block v_fma_mix*_f16 fusion
+            asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));
             if constexpr (sizeof(OutT) == 4) {
                 ((float4*)(y + (size_t)row * H))[i] = make_float4(r0, r1, r2, r3);
             } else {

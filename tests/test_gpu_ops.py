@@ -260,3 +260,21 @@ def test_gemm_persistent_multi_tile(api, epi, M, N, K):
     assert np.isfinite(out).all()
     bad = np.abs(out - ref) > tol * np.maximum(1.0, np.abs(ref))
     assert bad.mean() < (1e-4 if epi == "gelu" else 1e-7), f"{bad.sum()} mismatches, first at {np.argwhere(bad)[:4]}"
+
+
+@pytest.mark.parametrize("name,epi,N", [("plain", EPI_PLAIN, 1024), ("qkv", EPI_QKV, 3072), ("gelu", EPI_GELU, 4096),
+                                        ("gelu_small_tile", EPI_GELU, 384), ("resid", EPI_RESID, 1024)])
+def test_gemm_rows_do_not_depend_on_their_position(api, name, epi, N):
+    """A = [X; Y; X]: both X blocks must produce bit-identical outputs (B images == B independent forwards).  Caught a
+    real defect: hipcc fused 'add bias, round to f16' into v_fma_mixlo_f16 (single rounding) for some unrolled epilogue
+    instances only, so one element in ~1e5 depended on the row's lane."""
+    rng = np.random.default_rng(7)
+    T, K = 1374, 1024
+    X = _round(rng.standard_normal((T, K)), F16)
+    Y = _round(rng.standard_normal((T, K)), F16)
+    A = np.ascontiguousarray(np.concatenate([X, Y, X]))
+    W = _round(rng.standard_normal((N, K)) * 0.05, F16)
+    bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    out = np.zeros((3 * T, N), np.float32)
+    _gemm(api, F16, epi, A, W, bias, aux, out, 3 * T, N, K, N, qcols=N // 3, qscale=0.125)
+    assert np.array_equal(out[:T], out[2 * T:])
