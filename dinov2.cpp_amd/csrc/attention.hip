@@ -26,8 +26,11 @@
 
 namespace dinov2 {
 
-template <typename T>
-__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
+// LOG2: scores arrive multiplied by log2(e) (folded into the q scale by the QKV epilogue), so p = exp2(s - m) needs no
+// multiply.  launch_bounds(256, 2): allow up to 256 VGPRs -- with the default budget hipcc parked 128 values in AGPRs
+// and spent 255 v_accvgpr moves per key tile shuttling them (as many VALU ops as the softmax itself).
+template <typename T, bool LOG2>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
@@ -125,14 +128,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);
+        const float alpha = LOG2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(s[kb][r] - m_new);
+                const float pv = LOG2 ? __builtin_amdgcn_exp2f(s[kb][r] - m_new) : __expf(s[kb][r] - m_new);
                 s[kb][r] = pv;
                 psum += pv;
             }
@@ -186,13 +189,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ qk
     }
 }
 
-hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, hipStream_t st) {
+hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
+                            hipStream_t st) {
     if (H != nh * 64 || T <= 0 || B <= 0) return hipErrorInvalidValue;
     const dim3 grid((T + 127) / 128, nh, B), block(256);
-    if (dt == DT_F16)
-        hipLaunchKernelGGL(attention_kernel<_Float16>, grid, block, 0, st, (const _Float16*)qkv, (_Float16*)out, T, H);
-    else
-        hipLaunchKernelGGL(attention_kernel<__bf16>, grid, block, 0, st, (const __bf16*)qkv, (__bf16*)out, T, H);
+    if (dt == DT_F16) {
+        if (log2_scores) hipLaunchKernelGGL((attention_kernel<_Float16, true>), grid, block, 0, st, (const _Float16*)qkv, (_Float16*)out, T, H);
+        else hipLaunchKernelGGL((attention_kernel<_Float16, false>), grid, block, 0, st, (const _Float16*)qkv, (_Float16*)out, T, H);
+    } else {
+        if (log2_scores) hipLaunchKernelGGL((attention_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)qkv, (__bf16*)out, T, H);
+        else hipLaunchKernelGGL((attention_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)qkv, (__bf16*)out, T, H);
+    }
     return hipGetLastError();
 }
 

@@ -44,8 +44,10 @@ hipError_t launch_layernorm(DType dt, const float* x, const float* w, const floa
 hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int H, float eps,
                                 hipStream_t stream);
 
-// fused multi-head attention over token-major qkv [B*T, 3H] (T dtype, q pre-scaled), out [B*T, H]; hd == 64
-hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, hipStream_t stream);
+// fused multi-head attention over token-major qkv [B*T, 3H] (T dtype, q pre-scaled), out [B*T, H]; hd == 64.
+// log2_scores: q was scaled by log2(e)/sqrt(hd) instead of 1/sqrt(hd), so softmax uses exp2 directly.
+hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
+                            hipStream_t stream);
 
 // im2col of conv_2d_sk_p0: img f32 (layout 0 = BGR HWC interleaved, 1 = RGB CHW planar) -> col [B*P, Kpad] T,
 // patch vector order (c_rgb, ky, kx), zero padded to Kpad

@@ -582,12 +582,13 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
             Scope sc(s, K_QKV_GEMM);
             GemmArgs a{};
             a.A = s->ln; a.W = ly.qkv_w; a.bias = ly.qkv_b; a.out = s->qkv;
-            a.M = d.M; a.N = 3 * H; a.K = H; a.ldo = 3 * H; a.qcols = H; a.qscale = 0.125f;  // 1/sqrt(64), dinov2.cpp:626
+            a.M = d.M; a.N = 3 * H; a.K = H; a.ldo = 3 * H; a.qcols = H;
+            a.qscale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) (dinov2.cpp:626) x log2(e): softmax runs on exp2
             HIP_TRY(launch_gemm(dt, EPI_QKV, a, st));
         }
         {
             Scope sc(s, K_ATTENTION);
-            HIP_TRY(launch_attention(dt, s->qkv, s->att, B, d.T, H, nh, st));
+            HIP_TRY(launch_attention(dt, s->qkv, s->att, B, d.T, H, nh, true, st));
         }
         {
             Scope sc(s, K_OPROJ_GEMM);

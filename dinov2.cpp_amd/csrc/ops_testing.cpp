@@ -105,7 +105,7 @@ extern "C" int dinov2_hip_op_attention(int32_t dtype, const float* qkv, float* o
     OP_TRY(upload_as(dt, qkv, nq, dQ));
     OP_TRY(dO.alloc(no * 2));
     OP_TRY(hipMemset(dO.p, 0, no * 2));
-    OP_TRY(launch_attention(dt, dQ.p, dO.p, B, T, H, nh, nullptr));
+    OP_TRY(launch_attention(dt, dQ.p, dO.p, B, T, H, nh, false, nullptr));
     OP_TRY(hipDeviceSynchronize());
     OP_TRY(download_as(dt, dO.p, no, out));
     return 0;
@@ -236,9 +236,9 @@ extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, nullptr);
+    for (int i = 0; i < 3; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, true, nullptr);
     (void)hipEventRecord(e0, nullptr);
-    for (int i = 0; i < iters; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, nullptr);
+    for (int i = 0; i < iters; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, true, nullptr);
     (void)hipEventRecord(e1, nullptr);
     if (hipEventSynchronize(e1) != hipSuccess) return -1.f;
     float ms = 0.f;
