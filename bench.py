@@ -58,9 +58,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
     torch.cuda.set_device(local)
-    if world > 1:
+    # DINOV2_BENCH_FORCE_DIST=1 exercises the RCCL path (process group, arena broadcast, max-over-ranks) on a 1-GPU box
+    if world > 1 or os.environ.get("DINOV2_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     cfg = pkg.synth.CONFIGS[args.model]

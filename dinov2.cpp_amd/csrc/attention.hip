@@ -6,7 +6,7 @@
 // multiple of 32 WITHOUT masking them and is documented as less accurate; it is not the parity target.  Here the
 // key tail is masked to -inf.)
 //
-// Numerics: q (pre-scaled by the exact power of two 1/sqrt(64) in the QKV epilogue), k, v and the un-normalised
+// Numerics: q (pre-scaled by log2(e)/sqrt(64) in the QKV epilogue so that the softmax runs on exp2), k, v and the un-normalised
 // probabilities are MFMA inputs in the compute dtype (f16/bf16); scores, running max/sum and the output
 // accumulator are f32.  ggml keeps this block in f32 end to end -- the rounding is the documented tolerance source.
 //
@@ -21,6 +21,8 @@
 //     O^T keeps q on the lane axis, so the online-softmax rescale and the final 1/l are lane-local too.
 //   * K and V tiles are staged HBM -> LDS by global_load_lds_dwordx4, double buffered, 128-byte rows with the same
 //     16-byte-chunk XOR swizzle as the GEMM.
+#include <type_traits>
+
 #include "device_types.h"
 #include "kernels.h"
 
@@ -80,22 +82,43 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
     };
 
     const int sw = (ql >> 1) & 7;
+    // K fragment byte offsets inside a K tile, one per 16-wide k-step (+ kb * 4096 as an immediate)
+    int kaddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = ql * ROWB + (((ks * 2 + hh) ^ sw) << 4);
     // V^T gather for ds_read_b64_tr_b16: within each 16-lane group, lane t supplies the address of
-    // V[key0 + (t >> 2)][d0 + 4*(t & 3) .. +3] and receives V[key0 + 0..3][d0 + t]
+    // V[key0 + (t >> 2)][d0 + 4*(t & 3) .. +3] and receives V[key0 + 0..3][d0 + t].  key0 = 16t + 8*half + 4*hh: the row
+    // swizzle term ((row >> 1) & 7) does not depend on t, so four base offsets + t * 2048 as an immediate cover the tile.
     const int t16 = lane & 15;
-    const int vrow_l = t16 >> 2;                        // + key0
-    const int vcolb = (((lane >> 4) & 1) * 16 + (t16 & 3) * 4) * 2;  // byte column within a 32-d block
+    int vaddr[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int row0 = 8 * half + 4 * hh + (t16 >> 2);
+            const int colbyte = db * 64 + (((lane >> 4) & 1) * 16 + (t16 & 3) * 4) * 2;
+            vaddr[half][db] = row0 * ROWB + ((((colbyte >> 4) ^ ((row0 >> 1) & 7)) << 4) | (colbyte & 15));
+        }
 
     f32x16 o[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+    // -m_run broadcast over a 16-register tuple: fed as the C operand of the first MFMA of every score chain, so the
+    // accumulators come out as (s - m_run) and the softmax needs no subtraction; rewritten only when m_run moves.
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    // deferred max (online softmax): the reference point m_run only moves when a tile's maximum exceeds it by more than
+    // THR, so most tiles skip the O / l rescale.  p <= 2^THR stays far inside f16/bf16 range and keeps full relative
+    // precision; the first tile always takes the rescale branch (alpha = 0, whatever its maximum is).
+    constexpr float THR = LOG2 ? 8.0f : 5.5f;
 
     const int ntiles = (Ttok + KT - 1) / KT;
-    stage(0, 0);
-    for (int jt = 0; jt < ntiles; ++jt) {
+    auto tile = [&](int jt, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         __syncthreads();
-        if (jt + 1 < ntiles) stage((jt + 1) & 1, jt + 1);
+        if (!MASKED) stage((jt + 1) & 1, jt + 1);
         const char* sK = smem + (jt & 1) * 2 * TILEB;
         const char* sV = sK + TILEB;
 
@@ -104,15 +127,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const vec8 kf = *(const vec8*)(sK + (kb * 32 + ql) * ROWB + (((ks * 2 + hh) ^ sw) << 4));
-                s[kb] = E::mfma32(kf, qf[ks], s[kb]);
+                const vec8 kf = *(const vec8*)(sK + kaddr[ks] + kb * 32 * ROWB);
+                s[kb] = E::mfma32(kf, qf[ks], ks == 0 ? negm : s[kb]);
             }
         }
-        // key of s[kb][r] = jt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hh
-        if (jt == ntiles - 1) {
+        // s[kb][r] = score - m_run of key jt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hh; only the last tile has keys >= Ttok
+        if constexpr (MASKED) {
             const int kbase = jt * KT + 4 * hh;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -126,25 +147,33 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = LOG2 ? __builtin_amdgcn_exp2f(m_run - m_new) : __expf(m_run - m_new);
-        m_run = m_new;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));  // tile maximum relative to m_run
+        const bool first = jt == 0;          // m_run = 0 is not a real reference yet: take the tile maximum, whatever it is
+        const bool need = first || mx > THR;
+        if (__any(need)) {  // wave-uniform; lanes that do not need it shift by d = 0 (alpha = 1)
+            const float d = need ? mx : 0.f;
+            const float alpha = first ? 0.f : (LOG2 ? __builtin_amdgcn_exp2f(-d) : __expf(-d));
+            m_run += d;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
+                negm[r] = -m_run;
+                s[0][r] -= d;
+                s[1][r] -= d;
+            }
+        }
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = LOG2 ? __builtin_amdgcn_exp2f(s[kb][r] - m_new) : __expf(s[kb][r] - m_new);
+                const float pv = LOG2 ? __builtin_amdgcn_exp2f(s[kb][r]) : __expf(s[kb][r]);
                 s[kb][r] = pv;
                 psum += pv;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o[0][r] *= alpha;
-            o[1][r] *= alpha;
-        }
+        l_run += psum;
         // ---- O^T += V^T P^T : 4 k-steps of 16 keys; lane's 8 k-slots of step t = score regs (t&1)*8 .. +7 of
         //      block t>>1, i.e. keys 16t + 4hh + {0..3} and 16t + 8 + 4hh + {0..3}
 #pragma unroll
@@ -157,10 +186,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
                 vec8 vf;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const int row = 16 * t + 8 * half + 4 * hh + vrow_l;
-                    const int colbyte = db * 64 + vcolb;
-                    const int addr = row * ROWB + ((((colbyte >> 4) ^ ((row >> 1) & 7)) << 4) | (colbyte & 15));
-                    const s16x4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16((DINO_LDS_AS s16x4*)(sV + addr));
+                    const s16x4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (DINO_LDS_AS s16x4*)(sV + vaddr[half][db] + t * 16 * ROWB));
                     const vec4 v4 = __builtin_bit_cast(vec4, raw);
                     vf[half * 4 + 0] = v4[0];
                     vf[half * 4 + 1] = v4[1];
@@ -170,7 +197,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
                 o[db] = E::mfma32(vf, pf, o[db]);
             }
         }
-    }
+    };
+    stage(0, 0);
+    for (int jt = 0; jt + 1 < ntiles; ++jt) tile(jt, std::false_type{});
+    tile(ntiles - 1, std::true_type{});
 
     // ---- normalise and store: o[db][r] = O[q][d], d = db*32 + (r&3) + 8*(r>>2) + 4*hh ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
