@@ -82,6 +82,14 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) glds16(gw + wsrc[j], sW + (j * NW + wid) * 8 * ROWB);
     };
 
+    // one of the 8 wave-instructions of a K-tile (0-3: activation rows, 4-7: weight rows); j is a literal at every call
+    auto piece = [&](int buf, int kt, int j) {
+        if (DINO_GEMM_DBG & 2) return;
+        char* dst = smem + buf * STAGE + (j < 4 ? 0 : BM * ROWB) + ((j & 3) * NW + wid) * 8 * ROWB;
+        const char* src = (j < 4 ? (const char*)p.A + xsrc[j & 3] : (const char*)p.W + wsrc[j & 3]) + (size_t)kt * (BK * 2);
+        glds16(src, dst);
+    };
+
     const int wx = wid >> 2, ww = wid & 3;
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
@@ -144,50 +152,84 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #define DINO_WAIT_LGKM(N)                                   \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0);
-#define DINO_MFMAS(XF, WF)                                                                                            \
-    {                                                                                                                 \
-        if constexpr ((DINO_GEMM_DBG & 4) == 0) {                                                                     \
-            _Pragma("unroll") for (int i = 0; i < XREP; ++i) _Pragma("unroll") for (int j = 0; j < WREP; ++j)         \
-                acc[j][i] = E::mfma32(__builtin_bit_cast(vec8, WF[j]), __builtin_bit_cast(vec8, XF[i]), acc[j][i]);   \
-        } else {                                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < XREP; ++i) _Pragma("unroll") for (int j = 0; j < WREP; ++j)         \
-                acc[j][i][0] += (float)WF[j][0] * (float)XF[i][0];                                                    \
-        }                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                            \
+#define DINO_MFMA1(XF, WF, I, J) \
+    acc[J][I] = E::mfma32(__builtin_bit_cast(vec8, WF[J]), __builtin_bit_cast(vec8, XF[I]), acc[J][I]);
+    // eight MFMAs of one k-step with up to three staging instructions spread between them (PA before the 1st, PB after
+    // the 3rd, PC after the 6th; a statement or nothing).  A global_load_lds costs the issuing wave 60-185 cycles: issued
+    // as one burst of eight behind the barrier (both waves of a SIMD at once) they starved the matrix pipe for about a
+    // third of every K-tile (staging removed: 786 -> 1182 TFLOP/s).
+#define DINO_MFMAS_P(XF, WF, PA, PB, PC)           \
+    {                                              \
+        PA;                                        \
+        __builtin_amdgcn_sched_barrier(0);         \
+        DINO_MFMA1(XF, WF, 0, 0)                   \
+        DINO_MFMA1(XF, WF, 0, 1)                   \
+        DINO_MFMA1(XF, WF, 1, 0)                   \
+        __builtin_amdgcn_sched_barrier(0);         \
+        PB;                                        \
+        __builtin_amdgcn_sched_barrier(0);         \
+        DINO_MFMA1(XF, WF, 1, 1)                   \
+        DINO_MFMA1(XF, WF, 2, 0)                   \
+        DINO_MFMA1(XF, WF, 2, 1)                   \
+        __builtin_amdgcn_sched_barrier(0);         \
+        PC;                                        \
+        __builtin_amdgcn_sched_barrier(0);         \
+        DINO_MFMA1(XF, WF, 3, 0)                   \
+        DINO_MFMA1(XF, WF, 3, 1)                   \
+        __builtin_amdgcn_sched_barrier(0);         \
     }
+#define DINO_MFMAS(XF, WF) DINO_MFMAS_P(XF, WF, , , )
 
         __syncthreads();  // K-tile 0 of this tile has landed (vmcnt(0) precedes the barrier; also drains the previous
                           // tile's stores) and every wave has left the previous tile's epilogue slices in stage 1
         DINO_TS();
-        if (!(DINO_GEMM_DBG & 2)) stage(1, 1);
+        piece(1, 1, 0);
+        piece(1, 1, 1);
+        piece(1, 1, 2);
         DINO_LOAD_FRAGS(xf0, wf0, 0u, 0);
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = (unsigned)((kt + 1) & 1) * STAGE;
+            const int nb = (kt + 1) & 1;
+            const bool more = kt + 1 < nk;      // K-tile kt+1 exists: its pieces 0-2 were issued behind the last barrier,
+                                                // pieces 3-7 go out with the first two MFMA groups of this iteration
             DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
             DINO_WAIT_LGKM(6);                  // the older six (k-step 0) have returned
-            DINO_MFMAS(xf0, wf0);
+            DINO_MFMAS_P(xf0, wf0, if (more) piece(nb, kt + 1, 3), if (more) piece(nb, kt + 1, 4), if (more) piece(nb, kt + 1, 5));
             DINO_LOAD_FRAGS(xf0, wf0, cur, 2);
             DINO_WAIT_LGKM(6);
-            DINO_MFMAS(xf1, wf1);
+            DINO_MFMAS_P(xf1, wf1, if (more) piece(nb, kt + 1, 6), if (more) piece(nb, kt + 1, 7), );
             DINO_LOAD_FRAGS(xf1, wf1, cur, 3);
             DINO_WAIT_LGKM(6);
-            DINO_MFMAS(xf0, wf0);
+            DINO_MFMAS(xf0, wf0);               // no staging here: slack for K-tile kt+1 to land before the barrier
             // k-step-3 fragments (issued one MFMA group ago) must be in registers before the barrier: after it nobody
             // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
-            // of K-tile kt+1 (issued a whole K-tile ago) has landed; after the barrier everyone's has.
+            // of K-tile kt+1 has landed; after the barrier everyone's has.
             DINO_WAIT_LGKM(0);
+#if DINO_GEMM_DBG & 16  // timing experiment only (wrong results): barrier WITHOUT waiting for the in-flight K-tile
+            __builtin_amdgcn_s_barrier();
+#else
             __syncthreads();
-            if (kt + 2 < nk) {
-                if (!(DINO_GEMM_DBG & 2)) stage(kt & 1, kt + 2);
-            } else if (kt + 1 == nk && tix + nb_x < chunkn) {
-                // last K-tile of this output tile: stage 0 is idle -> start the NEXT tile's first K-tile now
-                const int nl = chunk0 + tix + nb_x;
-                set_tile((nl / ntn) * BM, (nl % ntn) * BN);
-                stage(0, 0);
-            }
+#endif
             DINO_LOAD_FRAGS(xf0, wf0, nxt, 0);  // after the last K-tile this reads LDS that is never used
             __builtin_amdgcn_sched_barrier(0);
-            DINO_MFMAS(xf1, wf1);
+            // MFMAs are never inside a branch (the accumulators would be copied at the join): only the staging
+            // instructions are conditional.  pk = K-tile to fetch (kt+2, or 0 of the NEXT output tile after the last
+            // barrier, when stage 0 is idle), pb = its stage.
+            const bool last = kt + 1 == nk;
+            const bool fetch = last ? (tix + nb_x < chunkn) : (kt + 2 < nk);
+            if (last && fetch) {
+                const int nl = chunk0 + tix + nb_x;
+                set_tile((nl / ntn) * BM, (nl % ntn) * BN);
+            }
+            const int pk = last ? 0 : kt + 2, pb = last ? 0 : (kt & 1);
+            DINO_MFMAS_P(xf1, wf1, if (fetch) piece(pb, pk, 0), if (fetch) piece(pb, pk, 1), if (fetch) piece(pb, pk, 2));
+        }
+        if (tix + nb_x < chunkn) {  // rest of the next tile's first K-tile: lands under the epilogue
+            piece(0, 0, 3);
+            piece(0, 0, 4);
+            piece(0, 0, 5);
+            piece(0, 0, 6);
+            piece(0, 0, 7);
         }
         DINO_WAIT_LGKM(0);
         DINO_TS();
@@ -195,6 +237,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #undef DINO_LOAD_FRAGS
 #undef DINO_WAIT_LGKM
 #undef DINO_MFMAS
+#undef DINO_MFMAS_P
+#undef DINO_MFMA1
 
         // ---- epilogue ----------------------------------------------------------------------------------------------
         // acc[j][i][4g + e] = C[m, n] with  m = m0 + wx*128 + i*32 + (lane & 31)
