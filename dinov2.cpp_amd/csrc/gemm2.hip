@@ -57,6 +57,18 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     const int chunk0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int chunkn = tq + (xcd < tr ? 1 : 0);
 
+    // logical tile id -> (m0, n0): groups of GM row panels are swept column by column, so the 32 tiles an XCD runs side
+    // by side form an 8 x 4 patch (8 activation panels + 4 weight panels live in its L2) instead of 2 x 16
+    // (2 + 16 panels): ~1.5x less refill traffic per K step.  Pure speed choice.
+    constexpr int GM = 8;
+    auto tile_mn = [&](int lid, int& m0, int& n0) {
+        const int g = lid / (GM * ntn), r = lid - g * (GM * ntn);
+        const int gm = ntm - g * GM < GM ? ntm - g * GM : GM;
+        const int n = r / gm, mi = r - n * gm;
+        m0 = (g * GM + mi) * BM;
+        n0 = n * BN;
+    };
+
     // ---- staging: 4 + 4 global_load_lds_dwordx4 per thread per K-tile, rows clamped to M ----
     unsigned xsrc[4], wsrc[4];  // byte offsets from p.A / p.W (both far below 4 GiB)
     const int srow = lane >> 3;
@@ -116,14 +128,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     const int nk = K / BK;  // even (checked by the launcher): the last K-tile sits in stage 1, stage 0 is free for the
                             // next tile's first K-tile while the epilogue works in stage 1
     if (bidx < chunkn) {
-        const int lid = chunk0 + bidx;
-        set_tile((lid / ntn) * BM, (lid % ntn) * BN);
+        int pm0, pn0;
+        tile_mn(chunk0 + bidx, pm0, pn0);
+        set_tile(pm0, pn0);
         stage(0, 0);
     }
     for (int tix = bidx; tix < chunkn; tix += nb_x) {
         DINO_TS();
-        const int lid = chunk0 + tix;
-        const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
+        int m0, n0;
+        tile_mn(chunk0 + tix, m0, n0);
 
         f32x16 acc[WREP][XREP];
 #pragma unroll
@@ -218,8 +231,9 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
             const bool last = kt + 1 == nk;
             const bool fetch = last ? (tix + nb_x < chunkn) : (kt + 2 < nk);
             if (last && fetch) {
-                const int nl = chunk0 + tix + nb_x;
-                set_tile((nl / ntn) * BM, (nl % ntn) * BN);
+                int nm0, nn0;
+                tile_mn(chunk0 + tix + nb_x, nm0, nn0);
+                set_tile(nm0, nn0);
             }
             const int pk = last ? 0 : kt + 2, pb = last ? 0 : (kt & 1);
             DINO_MFMAS_P(xf1, wf1, if (fetch) piece(pb, pk, 0), if (fetch) piece(pb, pk, 1), if (fetch) piece(pb, pk, 2));

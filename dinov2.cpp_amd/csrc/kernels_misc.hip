@@ -256,14 +256,25 @@ hipError_t launch_permute_bias(const float* src, float* dst, int N, int F, hipSt
 template <typename T>
 __global__ __launch_bounds__(256) void head_pool_kernel(const float* __restrict__ fin, float* __restrict__ feat, int T_,
                                                         int H, int first, float inv_div) {
+    // 64 columns x 4 token groups per block: lane = column (coalesced 256-byte rows), wave g sums tokens first+g, +4, ...
+    // in double; the four partial sums are combined in a fixed order (deterministic, same for every image).
+    __shared__ double part[4][64];
     const int b = blockIdx.y;
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= H) return;
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
     const float* f = fin + (size_t)b * T_ * H;
     double s = 0.0;
-    for (int t = first; t < T_; ++t) s += (double)f[(size_t)t * H + h];
-    feat[(size_t)b * 2 * H + h] = (float)(T)f[h];
-    feat[(size_t)b * 2 * H + H + h] = (float)(T)((float)s * inv_div);
+    if (h < H)
+        for (int t = first + g; t < T_; t += 4) s += (double)f[(size_t)t * H + h];
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && h < H) {
+        const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        float c = f[h], pm = (float)tot * inv_div;
+        asm volatile("" : "+v"(c), "+v"(pm));  // f32 values first, then the rounding to the weight type
+        feat[(size_t)b * 2 * H + h] = (float)(T)c;
+        feat[(size_t)b * 2 * H + H + h] = (float)(T)pm;
+    }
 }
 
 // one wave per class: logits[b, c] = bias[c] + sum_k W[c, k] * feat[b, k]
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(256) void head_softmax_kernel(const float* __restri
 
 hipError_t launch_head(DType dt, const float* fin, const void* W, const float* bias, float* feat, float* logits,
                        float* probs, int B, int T_, int H, int C, int first, float inv_div, hipStream_t st) {
-    const dim3 pg((H + 255) / 256, B), lg((C + 3) / 4, B);
+    const dim3 pg((H + 63) / 64, B), lg((C + 3) / 4, B);
     if (dt == DT_F16) {
         hipLaunchKernelGGL(head_pool_kernel<_Float16>, pg, dim3(256), 0, st, fin, feat, T_, H, first, inv_div);
         hipLaunchKernelGGL(head_logits_kernel<_Float16>, lg, dim3(256), 0, st, feat, (const _Float16*)W, bias, logits,
