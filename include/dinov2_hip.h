@@ -41,7 +41,10 @@ enum dinov2_hip_dtype { DINOV2_HIP_F16 = 0, DINOV2_HIP_BF16 = 1 };
 /* Input image memory layouts accepted by dinov2_hip_predict. */
 enum dinov2_hip_layout {
     DINOV2_HIP_BGR_HWC = 0, /* continuous CV_32FC3 cv::Mat as handed to dino_predict (dinov2.cpp:900, 914-931) */
-    DINOV2_HIP_RGB_CHW = 1  /* the planar "input" tensor dino_predict uploads        (dinov2.cpp:629-631, 933) */
+    DINOV2_HIP_RGB_CHW = 1, /* the planar "input" tensor dino_predict uploads        (dinov2.cpp:629-631, 933) */
+    DINOV2_HIP_U8_BGR_HWC = 2 /* RAW 8-bit BGR images [B, h, w, 3] as cv::imread returns them (inference.cpp:36): the library
+                                 runs dino_preprocess (or dino_classify_preprocess with DINOV2_HIP_CLASSIFY) on the device
+                                 first (dinov2.cpp:106-156); `data` points to uint8_t, height/width are the RAW size */
 };
 
 /* predict flags */
@@ -121,6 +124,14 @@ void *dinov2_hip_session_stream(dinov2_hip_session *session);
 /* -- predict (replaces dino_predict, dinov2.h:111-112 / dinov2.cpp:900-999) -------------------------- */
 int dinov2_hip_predict(dinov2_hip_session *session, const dinov2_hip_input *in, dinov2_hip_output *out,
                        uint32_t flags, char *err, size_t errlen);
+
+/* -- preprocessing (replaces dino_preprocess / dino_classify_preprocess, dinov2.h:93-96,
+ *    dinov2.cpp:106-156, without OpenCV).  mode 0: resize to ((w/p)+1)*p x ((h/p)+1)*p; mode 1: resize to 256x256 ignoring
+ *    aspect, centre-crop 224.  Input 8-bit BGR interleaved [h, w, 3]; output continuous f32 BGR [out_h, out_w, 3], /255,
+ *    bicubic (cv::INTER_CUBIC), (c - mean) / std with the reference's BGR<->mean indexing.  Host implementation; the same
+ *    arithmetic runs on the device for DINOV2_HIP_U8_BGR_HWC inputs. */
+int dinov2_hip_preprocess_size(int32_t mode, int32_t height, int32_t width, int32_t patch, int32_t *out_h, int32_t *out_w);
+int dinov2_hip_preprocess(int32_t mode, const uint8_t *bgr, int32_t height, int32_t width, int32_t patch, float *out);
 
 /* Host helper, exposed for parity tests: interpolate_pos_embed (dinov2.h:101-103 / dinov2.cpp:159-225).
  * out: [(1 + h_new*w_new), H] f32. */
