@@ -103,6 +103,8 @@ def lib():
     L.dinov2_hip_session_stream.restype = vp
     L.dinov2_hip_predict.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, cp, sz]
     L.dinov2_hip_interpolate_pos_embed.argtypes = [vp, i32, i32, vp]
+    L.dinov2_hip_preprocess_size.argtypes = [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.dinov2_hip_preprocess.argtypes = [i32, vp, i32, i32, i32, vp]
     L.dinov2_hip_session_profile.argtypes = [vp, i32]
     L.dinov2_hip_session_profile_read.argtypes = [vp, i32, C.POINTER(cp), C.POINTER(C.c_float), C.POINTER(i32)]
     L.dinov2_hip_debug_hidden.argtypes = [vp, C.POINTER(Input), i32, vp, cp, sz]
@@ -124,6 +126,36 @@ def lib():
 
 def _errbuf():
     return C.create_string_buffer(512)
+
+
+U8_BGR_HWC = 2
+
+
+def preprocess_size(mode: int, h: int, w: int, patch: int = 14) -> tuple[int, int]:
+    oh, ow = C.c_int32(), C.c_int32()
+    if lib().dinov2_hip_preprocess_size(mode, h, w, patch, C.byref(oh), C.byref(ow)) != 0:
+        raise DinoError(4, "preprocess_size")
+    return oh.value, ow.value
+
+
+def dino_preprocess(img_bgr_u8: np.ndarray, patch: int = 14) -> np.ndarray:
+    """dino_preprocess (dinov2.cpp:135-156) on the host: [h, w, 3] uint8 BGR -> f32 BGR [(h/p+1)*p, (w/p+1)*p, 3]."""
+    return _preprocess(0, img_bgr_u8, patch)
+
+
+def dino_classify_preprocess(img_bgr_u8: np.ndarray, patch: int = 14) -> np.ndarray:
+    """dino_classify_preprocess (dinov2.cpp:106-132): resize to 256x256 ignoring aspect, centre-crop 224, normalise."""
+    return _preprocess(1, img_bgr_u8, patch)
+
+
+def _preprocess(mode, img, patch):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 3 and img.shape[2] == 3
+    oh, ow = preprocess_size(mode, img.shape[0], img.shape[1], patch)
+    out = np.empty((oh, ow, 3), np.float32)
+    if lib().dinov2_hip_preprocess(mode, img.ctypes.data, img.shape[0], img.shape[1], patch, out.ctypes.data) != 0:
+        raise DinoError(4, "preprocess")
+    return out
 
 
 class Model:
@@ -197,15 +229,17 @@ class Session:
 
     def predict(self, images: np.ndarray, *, classify: bool = False, layout: int = RGB_CHW, topk: int = 0,
                 want=("cls", "patch_tokens", "logits", "probs")) -> dict:
-        """images: f32 host array [B,3,H,W] (RGB_CHW) or [B,H,W,3] (BGR_HWC).  Returns host numpy outputs."""
-        img = np.ascontiguousarray(images, dtype=np.float32)
+        """images: f32 host array [B,3,H,W] (RGB_CHW) or [B,H,W,3] (BGR_HWC), or RAW uint8 [B,h,w,3] BGR with
+        layout=U8_BGR_HWC (preprocessed on the device).  Returns host numpy outputs."""
+        img = np.ascontiguousarray(images, dtype=np.uint8 if layout == U8_BGR_HWC else np.float32)
         if img.ndim == 3:
             img = img[None]
         B = img.shape[0]
         hh, ww = (img.shape[2], img.shape[3]) if layout == RGB_CHW else (img.shape[1], img.shape[2])
         hp = self.model.hparams
         Hd, R, ps = hp.hidden_size, hp.num_register_tokens, hp.patch_size
-        P = (hh // ps) * (ww // ps)
+        nh, nw = preprocess_size(1 if classify else 0, hh, ww, ps) if layout == U8_BGR_HWC else (hh, ww)
+        P = (nh // ps) * (nw // ps)
         out = {}
         o = Output()
         if "cls" in want:

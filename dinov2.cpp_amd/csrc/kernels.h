@@ -53,6 +53,10 @@ hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, 
 // patch vector order (c_rgb, ky, kx), zero padded to Kpad
 hipError_t launch_im2col(DType dt, const float* img, void* col, int B, int Hh, int Ww, int patch, int Kpad, int layout,
                          hipStream_t stream);
+// dino_preprocess / dino_classify_preprocess on the device: u8 BGR [B,h,w,3] -> normalised f32 BGR [B,oh,ow,3]
+// (bicubic to rh x rw, crop at (y0, x0))
+hipError_t launch_preprocess_u8(const uint8_t* src, float* dst, int B, int h, int w, int rh, int rw, int y0, int x0, int oh,
+                                int ow, hipStream_t stream);
 // x[b*T + 0] = cls + pos[0]; x[b*T + 1 + r] = reg[r]
 hipError_t launch_init_tokens(float* x, const float* cls, const float* pos, const float* reg, int B, int T, int R,
                               int H, hipStream_t stream);

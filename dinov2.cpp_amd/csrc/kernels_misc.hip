@@ -140,6 +140,64 @@ hipError_t launch_im2col(DType dt, const float* img, void* col, int B, int Hh, i
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// dino_preprocess / dino_classify_preprocess on the device (/root/reference/dinov2.cpp:106-156), same arithmetic as
+// csrc/preprocess.cpp: u8 BGR [B,h,w,3] -> /255 -> bicubic (cv::INTER_CUBIC: A = -0.75, half-pixel centres, clamped
+// taps, horizontal pass first) to rh x rw -> crop (y0, x0, oh, ow) -> (c - mean[2-c]) / std[2-c] -> f32 BGR [B,oh,ow,3].
+// One thread per output pixel; the 16 source pixels of a thread are 4 runs of <= 4 adjacent BGR triples (L2 resident).
+// ---------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ void cubic_taps_dev(float t, float w[4]) {
+    const float A = -0.75f;
+    w[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    w[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    w[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    w[3] = 1.f - w[0] - w[1] - w[2];
+}
+
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, int B,
+                                                            int h, int w, int rh, int rw, int y0, int x0, int oh, int ow) {
+#pragma clang fp contract(off)  // same roundings as the host implementation
+    const size_t total = (size_t)B * oh * ow;
+    const float inv255 = (float)(1.0 / 255.0);
+    const float sx = (float)w / (float)rw, sy = (float)h / (float)rh;
+    const float mean[3] = {0.406f, 0.456f, 0.485f}, stdv[3] = {0.225f, 0.224f, 0.229f};  // indexed by BGR channel
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % ow), y = (int)((idx / ow) % oh), b = (int)(idx / ((size_t)ow * oh));
+        float fx = ((float)(x + x0) + 0.5f) * sx - 0.5f, fy = ((float)(y + y0) + 0.5f) * sy - 0.5f;
+        const int ix0 = (int)floorf(fx), iy0 = (int)floorf(fy);
+        float wx[4], wy[4];
+        cubic_taps_dev(fx - (float)ix0, wx);
+        cubic_taps_dev(fy - (float)iy0, wy);
+        const uint8_t* img = src + (size_t)b * h * w * 3;
+        float acc[3] = {0.f, 0.f, 0.f};
+        float rowv[4][3];
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            const int yy = min(max(iy0 - 1 + ky, 0), h - 1);
+            const uint8_t* row = img + (size_t)yy * w * 3;
+            const int xa = min(max(ix0 - 1, 0), w - 1), xb = min(max(ix0, 0), w - 1), xc = min(max(ix0 + 1, 0), w - 1),
+                      xd = min(max(ix0 + 2, 0), w - 1);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                rowv[ky][c] = (float)row[xa * 3 + c] * inv255 * wx[0] + (float)row[xb * 3 + c] * inv255 * wx[1] +
+                              (float)row[xc * 3 + c] * inv255 * wx[2] + (float)row[xd * 3 + c] * inv255 * wx[3];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            acc[c] = rowv[0][c] * wy[0] + rowv[1][c] * wy[1] + rowv[2][c] * wy[2] + rowv[3][c] * wy[3];
+            dst[idx * 3 + c] = (acc[c] - mean[c]) / stdv[c];
+        }
+    }
+}
+
+hipError_t launch_preprocess_u8(const uint8_t* src, float* dst, int B, int h, int w, int rh, int rw, int y0, int x0, int oh,
+                                int ow, hipStream_t st) {
+    const size_t total = (size_t)B * oh * ow;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks), dim3(256), 0, st, src, dst, B, h, w, rh, rw, y0, x0, oh, ow);
+    return hipGetLastError();
+}
+
 // x[b, 0] = cls + pos[0];  x[b, 1 + r] = register_tokens[r]  (no pos-embed on registers)  dinov2.cpp:662-685
 __global__ void init_tokens_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
                                    const float* __restrict__ reg, int T, int R, int H) {

@@ -638,12 +638,19 @@ int check_input(const dinov2_hip_session* s, const dinov2_hip_input* in, char* e
         return DINOV2_HIP_ERR_INVALID;
     }
     const int ps = (int)s->model->hp.patch_size;
+    if (in->layout == DINOV2_HIP_U8_BGR_HWC) {  // raw images: any size, preprocessed on the device
+        if (in->batch <= 0 || in->height <= 0 || in->width <= 0) {
+            set_err(err, errlen, "raw image input must have batch, height, width >= 1");
+            return DINOV2_HIP_ERR_INVALID;
+        }
+        return DINOV2_HIP_OK;
+    }
     if (in->batch <= 0 || in->height < ps || in->width < ps || in->height % ps || in->width % ps) {
         set_err(err, errlen, "input must be batch >= 1 and height/width positive multiples of patch_size %d (got %d x %d x %d)",
                 ps, in->batch, in->height, in->width);
         return DINOV2_HIP_ERR_INVALID;
     }
-    if (in->layout != DINOV2_HIP_BGR_HWC && in->layout != DINOV2_HIP_RGB_CHW) {
+    if (in->layout != DINOV2_HIP_BGR_HWC && in->layout != DINOV2_HIP_RGB_CHW) {  // (raw u8 returned above)
         set_err(err, errlen, "unknown input layout %d", in->layout);
         return DINOV2_HIP_ERR_INVALID;
     }
@@ -679,6 +686,7 @@ extern "C" void dinov2_hip_session_free(dinov2_hip_session* s) {
     drain_profile(s);
     for (auto e : s->free_events) (void)hipEventDestroy(e);
     if (s->ws) (void)hipFree(s->ws);
+    if (s->raw) (void)hipFree(s->raw);
     if (s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -739,17 +747,44 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
         return DINOV2_HIP_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m->device));
-    const int B = in->batch, h = in->height, w = in->width;
+    const int B = in->batch;
+    int h = in->height, w = in->width, layout = in->layout;
+    const bool raw_u8 = in->layout == DINOV2_HIP_U8_BGR_HWC;
+    if (raw_u8) {  // dino_classify_preprocess | dino_preprocess decide the network input size (dinov2.cpp:106-156)
+        int32_t oh, ow;
+        dinov2_hip_preprocess_size(classify ? 1 : 0, in->height, in->width, (int32_t)m->hp.patch_size, &oh, &ow);
+        h = oh;
+        w = ow;
+        layout = DINOV2_HIP_BGR_HWC;
+    }
     rc = ensure_workspace(s, B, h, w, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;
     hipStream_t st = s->stream;
 
     const float* img = in->data;
-    if (!in->on_device) {
+    if (raw_u8) {
+        const size_t nraw = (size_t)B * in->height * in->width * 3;
+        const uint8_t* src = reinterpret_cast<const uint8_t*>(in->data);
+        if (!in->on_device) {
+            if (nraw > s->raw_bytes) {
+                HIP_TRY(hipStreamSynchronize(st));
+                if (s->raw) HIP_TRY(hipFree(s->raw));
+                s->raw = nullptr;
+                s->raw_bytes = 0;
+                HIP_TRY(hipMalloc((void**)&s->raw, nraw));
+                s->raw_bytes = nraw;
+            }
+            HIP_TRY(hipMemcpyAsync(s->raw, src, nraw, hipMemcpyHostToDevice, st));
+            src = s->raw;
+        }
+        const int rh = classify ? 256 : h, rw = classify ? 256 : w;
+        HIP_TRY(launch_preprocess_u8(src, s->img, B, in->height, in->width, rh, rw, (rh - h) / 2, (rw - w) / 2, h, w, st));
+        img = s->img;
+    } else if (!in->on_device) {
         HIP_TRY(hipMemcpyAsync(s->img, in->data, sizeof(float) * 3 * (size_t)B * h * w, hipMemcpyHostToDevice, st));
         img = s->img;
     }
-    rc = forward(s, img, B, h, w, in->layout, classify, (int)m->hp.num_hidden_layers, true, err, errlen);
+    rc = forward(s, img, B, h, w, layout, classify, (int)m->hp.num_hidden_layers, true, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;
     if (!out) return DINOV2_HIP_OK;
 

@@ -48,6 +48,8 @@ struct dinov2_hip_session {
     bool own_stream = false;
     char* ws = nullptr;
     size_t ws_bytes = 0;
+    uint8_t* raw = nullptr;  // raw 8-bit images for DINOV2_HIP_U8_BGR_HWC inputs
+    size_t raw_bytes = 0;
     // carved views (valid for cur_* shape)
     int cur_b = 0, cur_h = 0, cur_w = 0;
     float *img = nullptr, *x = nullptr, *fin = nullptr, *feat = nullptr, *logits = nullptr, *probs = nullptr,

@@ -1,0 +1,79 @@
+"""dino_preprocess / dino_classify_preprocess without OpenCV.
+CPU: the C-ABI host implementation vs the numpy oracle (float64) vs torch bicubic (independent implementation).
+GPU: raw 8-bit images handed to predict (device preprocessing kernel) == host preprocessing + predict."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import preprocess_np as PP
+
+
+def _images():
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:408, 0:612]
+    smooth = np.stack([(xx * 255 // 611), (yy * 255 // 407), ((xx + yy) % 256)], -1).astype(np.uint8)  # tench.jpg-sized
+    return {"noise_300x200": rng.integers(0, 256, (300, 200, 3), dtype=np.uint8), "smooth_408x612": smooth,
+            "tiny_20x33": rng.integers(0, 256, (20, 33, 3), dtype=np.uint8),
+            "multiple_of_14": rng.integers(0, 256, (518, 518, 3), dtype=np.uint8)}
+
+
+@pytest.mark.parametrize("name", list(_images()))
+def test_host_preprocess_matches_oracle(api, name):
+    img = _images()[name]
+    for mode, fn in ((0, api.dino_preprocess), (1, api.dino_classify_preprocess)):
+        got = fn(img)
+        exp = PP.preprocess(mode, img)
+        assert got.shape == exp.shape == (*PP.preprocess_size(mode, img.shape[0], img.shape[1], 14), 3)
+        # f32 source coordinates and weights (as in cv::resize) vs the float64 oracle: <= ~1e-4 on white-noise images
+        assert np.abs(got - exp).max() < 3e-4, (name, mode)
+
+
+def test_resize_quirks(api):
+    """The feature resize ALWAYS grows by one patch, even from a multiple of 14 (518 -> 532, dinov2.cpp:140-141; SURVEY
+    fact 5); classify always yields 224x224 whatever the aspect ratio (dinov2.cpp:111-119)."""
+    assert api.preprocess_size(0, 518, 518) == (532, 532)
+    assert api.preprocess_size(0, 408, 612) == (420, 616)  # tench.jpg -> the 616x420 pca_visual.jpg of the reference
+    assert api.preprocess_size(1, 408, 612) == (224, 224)
+    assert api.dino_classify_preprocess(_images()["noise_300x200"]).shape == (224, 224, 3)
+
+
+def test_bgr_mean_std_indexing(api):
+    """Channel i of the BGR image is normalised with mean[2 - i], std[2 - i] (dinov2.cpp:124-127)."""
+    img = np.zeros((28, 28, 3), np.uint8)
+    img[..., 0] = 255  # pure blue
+    out = api.dino_preprocess(img)
+    c = out[20, 20]
+    np.testing.assert_allclose(c, [(1 - 0.406) / 0.225, (0 - 0.456) / 0.224, (0 - 0.485) / 0.229], rtol=1e-5)
+
+
+def test_bicubic_equals_torch(api):
+    """cv::INTER_CUBIC restatement == torch bicubic (align_corners=False, no antialias), up- and down-scaling."""
+    torch = pytest.importorskip("torch")
+    img = _images()["noise_300x200"]
+    got = api.dino_preprocess(img)
+    x = torch.from_numpy(img.astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    y = torch.nn.functional.interpolate(x, size=got.shape[:2], mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+    exp = (y - np.array([0.406, 0.456, 0.485], np.float32)) / np.array([0.225, 0.224, 0.229], np.float32)
+    assert np.abs(got - exp).max() < 3e-4
+    got = api.dino_classify_preprocess(img)  # 300x200 -> 256x256 (down in y, up in x) -> crop
+    y = torch.nn.functional.interpolate(x, size=(256, 256), mode="bicubic", align_corners=False)[0].permute(1, 2, 0).numpy()
+    exp = ((y - np.array([0.406, 0.456, 0.485], np.float32)) / np.array([0.225, 0.224, 0.229], np.float32))[16:240, 16:240]
+    assert np.abs(got - exp).max() < 3e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("classify", [False, True])
+def test_device_preprocess_equals_host_then_predict(api, golden_dir, classify):
+    """inference.cpp:36-65 end to end: raw BGR bytes -> (device) preprocess -> forward == host preprocess -> forward."""
+    model = api.Model(os.path.join(golden_dir, "tiny_gelu_reg4.gguf"), classify=True)
+    sess = api.Session(model)
+    rng = np.random.default_rng(8)
+    raw = rng.integers(0, 256, (2, 90, 123, 3), dtype=np.uint8)
+    a = sess.predict(raw, classify=classify, layout=api.U8_BGR_HWC)
+    pre = np.stack([(api.dino_classify_preprocess if classify else api.dino_preprocess)(r) for r in raw])
+    b = sess.predict(pre, classify=classify, layout=api.BGR_HWC)
+    assert a["patch_tokens"].shape == b["patch_tokens"].shape
+    assert np.abs(a["patch_tokens"] - b["patch_tokens"]).max() < 2e-3
+    if classify:
+        assert np.abs(a["logits"] - b["logits"]).max() < 1e-3
