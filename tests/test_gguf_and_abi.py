@@ -200,3 +200,28 @@ def test_cpp_compat_shim_runs(tmp_path, golden_dir):
     assert r.returncode == 0 and r.stdout.count(" > label_") == 3 and "hidden_size            = 128" in r.stdout, r.stdout + r.stderr
     r = subprocess.run([exe, os.path.join(golden_dir, "tiny_gelu_reg4.gguf")], capture_output=True, text=True)
     assert r.returncode == 0 and "patch_tokens: 30 x 128" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("itype,tname", [(2, "q4_0"), (3, "q4_1"), (6, "q5_0"), (7, "q5_1"), (8, "q8_0")])
+def test_quantize_tool(pkg, tmp_path, itype, tname):
+    """`quantize` counterpart (dinov2.cpp:355-453): only 2-D `*.weight` tensors change type, the conv kernel / 1-D /
+    embedding tensors are copied, ftype KV is overwritten, and the blocks equal a direct quantisation of the f16 values."""
+    from importlib import import_module
+    from __graft_entry__ import PKG_NAME
+    Q = import_module(PKG_NAME + ".quantize")
+    src, dst = str(tmp_path / "f16.gguf"), str(tmp_path / f"{tname}.gguf")
+    pkg.synth.write_synthetic_gguf(src, "tiny", registers=4, num_classes=8, seed=9)
+    assert Q.dino_model_quantize(src, dst, itype)
+    a, b = G.GGUFFile(src), G.GGUFFile(dst)
+    assert list(a.kv) == list(b.kv) and b.u32("ftype") == itype and a.u32("ftype") == 1
+    assert list(a.tensors) == list(b.tensors)
+    for name, ta in a.tensors.items():
+        tb = b.tensors[name]
+        assert ta.ne == tb.ne
+        if name.endswith("weight") and len([d for d in ta.ne if d > 1]) == 2 and "patch_embeddings" not in name \
+                and "norm" not in name:
+            assert tb.gtype == itype, name
+            assert np.array_equal(tb.raw, pkg.gguf_writer.quantize(ta.to_f32(), itype).reshape(-1)), name
+        else:
+            assert tb.gtype == ta.gtype and np.array_equal(ta.raw, tb.raw), name
+    assert not Q.dino_model_quantize(src, dst, 5)  # invalid type id -> False, like dinov2.cpp:365-373
