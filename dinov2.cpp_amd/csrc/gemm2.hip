@@ -103,6 +103,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     };
 
     const int wx = wid >> 2, ww = wid & 3;
+    const int grp = wid >> 2;  // waves 0-3 / 4-7: the two waves that share each SIMD
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
     const int xoff = (wx * 128 + fr) * ROWB;
@@ -167,31 +168,44 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
 #define DINO_MFMA1(XF, WF, I, J) \
     acc[J][I] = E::mfma32(__builtin_bit_cast(vec8, WF[J]), __builtin_bit_cast(vec8, XF[I]), acc[J][I]);
-    // eight MFMAs of one k-step with up to three staging instructions spread between them (PA before the 1st, PB after
-    // the 3rd, PC after the 6th; a statement or nothing).  A global_load_lds costs the issuing wave 60-185 cycles: issued
-    // as one burst of eight behind the barrier (both waves of a SIMD at once) they starved the matrix pipe for about a
-    // third of every K-tile (staging removed: 786 -> 1182 TFLOP/s).
-#define DINO_MFMAS_P(XF, WF, PA, PB, PC)           \
+    // Eight MFMAs of one k-step with staging instructions in four slots: S0 before the 1st MFMA, S1 after the 3rd, S2
+    // after the 6th, S3 after the 8th.  A global_load_lds occupies its wave's issue port for ~60-185 cycles, so wave
+    // group 0 (waves 0-3) stages in S0,S1,S2 and group 1 (waves 4-7, their SIMD partners) in S1,S2,S3: the two waves of a
+    // SIMD are not both stuck in a staging instruction at the same moment.  Measured honestly: a burst of eight behind
+    // the barrier vs. these slots is worth ~5 % in the micro-benchmark and nothing in-model; with the staging removed
+    // altogether the kernel runs 786 -> 1182 TFLOP/s (cycles -20 %, clock +17 %), and neither the load latency (no-wait
+    // experiment), nor the LDS reads (free), nor the barrier (6 %) explains it -- see profiles/r01_gemm_tuning.md.
+#define DINO_MFMAS_P(XF, WF, S0, S1, S2, S3)       \
     {                                              \
-        PA;                                        \
+        S0;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
         DINO_MFMA1(XF, WF, 0, 0)                   \
         DINO_MFMA1(XF, WF, 0, 1)                   \
         DINO_MFMA1(XF, WF, 1, 0)                   \
         __builtin_amdgcn_sched_barrier(0);         \
-        PB;                                        \
+        S1;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
         DINO_MFMA1(XF, WF, 1, 1)                   \
         DINO_MFMA1(XF, WF, 2, 0)                   \
         DINO_MFMA1(XF, WF, 2, 1)                   \
         __builtin_amdgcn_sched_barrier(0);         \
-        PC;                                        \
+        S2;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
         DINO_MFMA1(XF, WF, 3, 0)                   \
         DINO_MFMA1(XF, WF, 3, 1)                   \
         __builtin_amdgcn_sched_barrier(0);         \
+        S3;                                        \
+        __builtin_amdgcn_sched_barrier(0);         \
     }
-#define DINO_MFMAS(XF, WF) DINO_MFMAS_P(XF, WF, , , )
+    // slot helpers: piece ja for group 0 / piece jb for group 1 of K-tile KT into stage BUF when COND holds
+#define DINO_SLOT_A(COND, BUF, KT, JA) if ((COND) && grp == 0) piece(BUF, KT, JA)
+#define DINO_SLOT_B(COND, BUF, KT, JB) if ((COND) && grp == 1) piece(BUF, KT, JB)
+#define DINO_SLOT_AB(COND, BUF, KT, JA, JB) \
+    if (COND) {                             \
+        if (grp == 0) piece(BUF, KT, JA);   \
+        else piece(BUF, KT, JB);            \
+    }
+#define DINO_MFMAS(XF, WF) DINO_MFMAS_P(XF, WF, , , , )
 
         __syncthreads();  // K-tile 0 of this tile has landed (vmcnt(0) precedes the barrier; also drains the previous
                           // tile's stores) and every wave has left the previous tile's epilogue slices in stage 1
@@ -207,10 +221,12 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                                                 // pieces 3-7 go out with the first two MFMA groups of this iteration
             DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
             DINO_WAIT_LGKM(6);                  // the older six (k-step 0) have returned
-            DINO_MFMAS_P(xf0, wf0, if (more) piece(nb, kt + 1, 3), if (more) piece(nb, kt + 1, 4), if (more) piece(nb, kt + 1, 5));
+            DINO_MFMAS_P(xf0, wf0, DINO_SLOT_A(more, nb, kt + 1, 3), DINO_SLOT_AB(more, nb, kt + 1, 4, 3),
+                         DINO_SLOT_AB(more, nb, kt + 1, 5, 4), DINO_SLOT_B(more, nb, kt + 1, 5));
             DINO_LOAD_FRAGS(xf0, wf0, cur, 2);
             DINO_WAIT_LGKM(6);
-            DINO_MFMAS_P(xf1, wf1, if (more) piece(nb, kt + 1, 6), if (more) piece(nb, kt + 1, 7), );
+            DINO_MFMAS_P(xf1, wf1, DINO_SLOT_A(more, nb, kt + 1, 6), DINO_SLOT_AB(more, nb, kt + 1, 7, 6),
+                         DINO_SLOT_B(more, nb, kt + 1, 7), );
             DINO_LOAD_FRAGS(xf1, wf1, cur, 3);
             DINO_WAIT_LGKM(6);
             DINO_MFMAS(xf0, wf0);               // no staging here: slack for K-tile kt+1 to land before the barrier
@@ -218,7 +234,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
             // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
             // of K-tile kt+1 has landed; after the barrier everyone's has.
             DINO_WAIT_LGKM(0);
-#if DINO_GEMM_DBG & 16  // timing experiment only (wrong results): barrier WITHOUT waiting for the in-flight K-tile
+#if DINO_GEMM_DBG & 64  // timing experiment only: no barrier at all
+#elif DINO_GEMM_DBG & 16  // timing experiment only (wrong results): barrier WITHOUT waiting for the in-flight K-tile
             __builtin_amdgcn_s_barrier();
 #else
             __syncthreads();
@@ -236,7 +253,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                 set_tile(nm0, nn0);
             }
             const int pk = last ? 0 : kt + 2, pb = last ? 0 : (kt & 1);
-            DINO_MFMAS_P(xf1, wf1, if (fetch) piece(pb, pk, 0), if (fetch) piece(pb, pk, 1), if (fetch) piece(pb, pk, 2));
+            DINO_MFMAS_P(xf1, wf1, DINO_SLOT_A(fetch, pb, pk, 0), DINO_SLOT_AB(fetch, pb, pk, 1, 0), DINO_SLOT_AB(fetch, pb, pk, 2, 1),
+                         DINO_SLOT_B(fetch, pb, pk, 2));
         }
         if (tix + nb_x < chunkn) {  // rest of the next tile's first K-tile: lands under the epilogue
             piece(0, 0, 3);
@@ -251,6 +269,9 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #undef DINO_LOAD_FRAGS
 #undef DINO_WAIT_LGKM
 #undef DINO_MFMAS
+#undef DINO_SLOT_A
+#undef DINO_SLOT_B
+#undef DINO_SLOT_AB
 #undef DINO_MFMAS_P
 #undef DINO_MFMA1
 
