@@ -21,6 +21,7 @@
 //     O^T keeps q on the lane axis, so the online-softmax rescale and the final 1/l are lane-local too.
 //   * K and V tiles are staged HBM -> LDS by global_load_lds_dwordx4, double buffered, 128-byte rows with the same
 //     16-byte-chunk XOR swizzle as the GEMM.
+#include <cstdlib>
 #include <type_traits>
 
 #include "device_types.h"
@@ -31,8 +32,8 @@ namespace dinov2 {
 // LOG2: scores arrive multiplied by log2(e) (folded into the q scale by the QKV epilogue), so p = exp2(s - m) needs no
 // multiply.  launch_bounds(256, 2): allow up to 256 VGPRs -- with the default budget hipcc parked 128 values in AGPRs
 // and spent 255 v_accvgpr moves per key tile shuttling them (as many VALU ops as the softmax itself).
-template <typename T, bool LOG2>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
+template <typename T, bool LOG2, int NWV>
+__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
     const char* base = (const char*)(qkv + (size_t)b * Ttok * H3);
 
     const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = blockIdx.x * 128 + wid * 32 + ql;
+    const int qrow = blockIdx.x * (NWV * 32) + wid * 32 + ql;
     const int qrc = qrow < Ttok ? qrow : Ttok - 1;
 
     // Q^T fragments (B operand): lane holds q[qrow][16*ks + 8*hh + 0..7]
@@ -61,23 +62,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
 
     // staging: a wave-instruction covers 8 rows x 128 B; 4 waves x 2 instructions = 64 rows, for K and for V
     const int srow = lane >> 3;
-    int strow[2];
-    int stlc[2];
+    constexpr int SI = 8 / NWV;  // staging wave-instructions per wave per matrix (8 rows each, 64 rows per tile)
+    int strow[SI];
+    int stlc[SI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        strow[j] = (j * 4 + wid) * 8 + srow;
+    for (int j = 0; j < SI; ++j) {
+        strow[j] = (j * NWV + wid) * 8 + srow;
         stlc[j] = ((lane & 7) ^ ((strow[j] >> 1) & 7)) * 16;
     }
     auto stage = [&](int buf, int jt) {
         char* sK = smem + buf * 2 * TILEB;
         char* sV = sK + TILEB;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < SI; ++j) {
             int key = jt * KT + strow[j];
             key = key < Ttok ? key : Ttok - 1;  // tail rows re-read the last key; masked below
             const char* g = base + ((size_t)key * H3 + h * 64) * 2 + stlc[j];
-            glds16(g + (size_t)H * 2, sK + (j * 4 + wid) * 8 * ROWB);
-            glds16(g + (size_t)H * 4, sV + (j * 4 + wid) * 8 * ROWB);
+            glds16(g + (size_t)H * 2, sK + (j * NWV + wid) * 8 * ROWB);
+            glds16(g + (size_t)H * 4, sV + (j * NWV + wid) * 8 * ROWB);
         }
     };
 
@@ -222,14 +224,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const T* __restrict__
 hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
                             hipStream_t st) {
     if (H != nh * 64 || T <= 0 || B <= 0) return hipErrorInvalidValue;
-    const dim3 grid((T + 127) / 128, nh, B), block(256);
+    // 8 waves (256 queries) per workgroup halve the K/V staging per query; 4 waves waste less on the ragged last query
+    // block.  DINOV2_HIP_ATTN_WAVES=4|8 overrides (tuning aid).
+    static const int forced = [] {
+        const char* e = getenv("DINOV2_HIP_ATTN_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    const int nwv = forced == 4 || forced == 8 ? forced : 4;  // A/B on MI355X: equal within noise (0.41-0.43 ms)
+    const dim3 grid((T + nwv * 32 - 1) / (nwv * 32), nh, B), block(nwv * 64);
+#define DINO_ATT(TT, LG, NW) \
+    hipLaunchKernelGGL((attention_kernel<TT, LG, NW>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
     if (dt == DT_F16) {
-        if (log2_scores) hipLaunchKernelGGL((attention_kernel<_Float16, true>), grid, block, 0, st, (const _Float16*)qkv, (_Float16*)out, T, H);
-        else hipLaunchKernelGGL((attention_kernel<_Float16, false>), grid, block, 0, st, (const _Float16*)qkv, (_Float16*)out, T, H);
+        if (nwv == 8) { if (log2_scores) DINO_ATT(_Float16, true, 8); else DINO_ATT(_Float16, false, 8); }
+        else { if (log2_scores) DINO_ATT(_Float16, true, 4); else DINO_ATT(_Float16, false, 4); }
     } else {
-        if (log2_scores) hipLaunchKernelGGL((attention_kernel<__bf16, true>), grid, block, 0, st, (const __bf16*)qkv, (__bf16*)out, T, H);
-        else hipLaunchKernelGGL((attention_kernel<__bf16, false>), grid, block, 0, st, (const __bf16*)qkv, (__bf16*)out, T, H);
+        if (nwv == 8) { if (log2_scores) DINO_ATT(__bf16, true, 8); else DINO_ATT(__bf16, false, 8); }
+        else { if (log2_scores) DINO_ATT(__bf16, true, 4); else DINO_ATT(__bf16, false, 4); }
     }
+#undef DINO_ATT
     return hipGetLastError();
 }
 

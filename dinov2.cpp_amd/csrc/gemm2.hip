@@ -73,6 +73,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     unsigned xsrc[4], wsrc[4];  // byte offsets from p.A / p.W (both far below 4 GiB)
     const int srow = lane >> 3;
     auto set_tile = [&](int m0, int n0) {
+#if DINO_GEMM_DBG & 256  // timing experiment only: every tile stages tile (0,0) -> operands stay L2-resident
+        m0 = 0;
+        n0 = 0;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = (j * NW + wid) * 8 + srow;
@@ -166,6 +170,11 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #define DINO_WAIT_LGKM(N)                                   \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); \
     __builtin_amdgcn_sched_barrier(0);
+#if DINO_GEMM_DBG & 512  // experiment: raise the wave's priority around its MFMA runs
+#define DINO_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#else
+#define DINO_PRIO(P)
+#endif
 #define DINO_MFMA1(XF, WF, I, J) \
     acc[J][I] = E::mfma32(__builtin_bit_cast(vec8, WF[J]), __builtin_bit_cast(vec8, XF[I]), acc[J][I]);
     // Eight MFMAs of one k-step with staging instructions in four slots: S0 before the 1st MFMA, S1 after the 3rd, S2
@@ -179,20 +188,26 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     {                                              \
         S0;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
+        DINO_PRIO(1);                              \
         DINO_MFMA1(XF, WF, 0, 0)                   \
         DINO_MFMA1(XF, WF, 0, 1)                   \
         DINO_MFMA1(XF, WF, 1, 0)                   \
+        DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S1;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
+        DINO_PRIO(1);                              \
         DINO_MFMA1(XF, WF, 1, 1)                   \
         DINO_MFMA1(XF, WF, 2, 0)                   \
         DINO_MFMA1(XF, WF, 2, 1)                   \
+        DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S2;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
+        DINO_PRIO(1);                              \
         DINO_MFMA1(XF, WF, 3, 0)                   \
         DINO_MFMA1(XF, WF, 3, 1)                   \
+        DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S3;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
