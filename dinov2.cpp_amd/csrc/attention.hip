@@ -21,13 +21,60 @@
 //     O^T keeps q on the lane axis, so the online-softmax rescale and the final 1/l are lane-local too.
 //   * K and V tiles are staged HBM -> LDS by global_load_lds_dwordx4, double buffered, 128-byte rows with the same
 //     16-byte-chunk XOR swizzle as the GEMM.
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
+#include <vector>
 
 #include "device_types.h"
 #include "kernels.h"
 
 namespace dinov2 {
+
+// -DDINO_ATT_PROF: per-phase s_memtime sums (tuning builds only; `make variant V=prof VFLAGS=-DDINO_ATT_PROF`)
+#ifdef DINO_ATT_PROF
+__device__ unsigned long long g_att_prof[32768 * 8];
+#define DINO_TS(i) { const unsigned long long t__ = __builtin_readcyclecounter(); prof_acc[i] += t__ - prof_t; prof_t = t__; }
+#define DINO_TS_INIT unsigned long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long prof_t = __builtin_readcyclecounter();
+#define DINO_TS_FLUSH if (lane == 0) { const int w__ = (blockIdx.x * 4 + wid) & 32767; for (int i__ = 0; i__ < 8; ++i__) g_att_prof[w__ * 8 + i__] = prof_acc[i__]; }
+#else
+#define DINO_TS(i)
+#define DINO_TS_INIT
+#define DINO_TS_FLUSH
+#endif
+
+// max of three without the v_max(x, x) NaN-quieting moves hipcc adds around fmaxf in IEEE mode (scores are finite or -inf)
+static __device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// max over the two 32-lane halves (lanes l and l + 32 hold the same query): v_permlane32_swap hands every lane both halves'
+// values without the LDS round trip of ds_bpermute
+static __device__ __forceinline__ float max_halves(float m) {
+    // one asm block, padded on both sides: hipcc's hazard recogniser does not look inside the asm statements that produce /
+    // consume these registers, and v_permlane32_swap needs wait states after a VALU write and before a VALU read.
+    // After the swap: a = lower half's value in every lane, b = upper half's.
+    float a = m, b = m;
+    asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "+v"(b));
+    return max3f(a, b, b);
+}
+// maximum of the 32 scores a lane holds: 16 v_max3 in four independent chains + 2 to join them
+static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
+    float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[0][3], s[0][4], s[0][5]);
+    float m2 = max3f(s[0][6], s[0][7], s[0][8]), m3 = max3f(s[0][9], s[0][10], s[0][11]);
+    m0 = max3f(m0, s[0][12], s[0][13]);
+    m1 = max3f(m1, s[0][14], s[0][15]);
+    m2 = max3f(m2, s[1][0], s[1][1]);
+    m3 = max3f(m3, s[1][2], s[1][3]);
+    m0 = max3f(m0, s[1][4], s[1][5]);
+    m1 = max3f(m1, s[1][6], s[1][7]);
+    m2 = max3f(m2, s[1][8], s[1][9]);
+    m3 = max3f(m3, s[1][10], s[1][11]);
+    m0 = max3f(m0, s[1][12], s[1][13]);
+    m1 = max3f(m1, s[1][14], s[1][15]);
+    return max3f(max3f(m0, m1, m2), m3, m3);
+}
 
 // LOG2: scores arrive multiplied by log2(e) (folded into the q scale by the QKV epilogue), so p = exp2(s - m) needs no
 // multiply.  launch_bounds(256, 2): allow up to 256 VGPRs -- with the default budget hipcc parked 128 values in AGPRs
@@ -45,13 +92,20 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    DINO_TS_INIT
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.z, h = blockIdx.y;
+    // 1-D grid, XCD-aware: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, which would put the query
+    // blocks of one (image, head) on 8 different L2s and fetch its K/V from HBM 8 times (measured: 1.6 GB per launch against
+    // 0.36 GB algorithmic, i.e. the kernel ran at HBM speed).  xcd_remap gives each XCD a contiguous range of logical ids,
+    // so all query blocks of a head share one L2.
+    const int nqb = (Ttok + NWV * 32 - 1) / (NWV * 32), nhd = H >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qb = lid % nqb, h = (lid / nqb) % nhd, b = lid / (nqb * nhd);
     const int H3 = 3 * H;
     const char* base = (const char*)(qkv + (size_t)b * Ttok * H3);
 
     const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = blockIdx.x * (NWV * 32) + wid * 32 + ql;
+    const int qrow = qb * (NWV * 32) + wid * 32 + ql;
     const int qrc = qrow < Ttok ? qrow : Ttok - 1;
 
     // Q^T fragments (B operand): lane holds q[qrow][16*ks + 8*hh + 0..7]
@@ -60,26 +114,30 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
     for (int ks = 0; ks < 4; ++ks)
         qf[ks] = *(const vec8*)(base + ((size_t)qrc * H3 + h * 64 + ks * 16 + hh * 8) * 2);
 
-    // staging: a wave-instruction covers 8 rows x 128 B; 4 waves x 2 instructions = 64 rows, for K and for V
+    // staging: a wave-instruction covers 8 rows x 128 B; NWV waves x SI instructions = 64 rows, for K and for V.  Per-lane
+    // 32-bit byte offsets from the (image, head) K base, advanced by one tile per step and clamped to the last key (tail rows
+    // re-read it and are masked below): 2 VALU per instruction instead of a 64-bit multiply-add chain.
     const int srow = lane >> 3;
-    constexpr int SI = 8 / NWV;  // staging wave-instructions per wave per matrix (8 rows each, 64 rows per tile)
-    int strow[SI];
-    int stlc[SI];
+    constexpr int SI = 8 / NWV;
+    const char* kbase = base + ((size_t)h * 64 + H) * 2;
+    const unsigned rowb = (unsigned)H3 * 2u, vdelta = (unsigned)H * 2u;
+    unsigned stoff[SI], stmax[SI];
 #pragma unroll
     for (int j = 0; j < SI; ++j) {
-        strow[j] = (j * NWV + wid) * 8 + srow;
-        stlc[j] = ((lane & 7) ^ ((strow[j] >> 1) & 7)) * 16;
+        const int r = (j * NWV + wid) * 8 + srow;
+        const unsigned lc = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        stoff[j] = (unsigned)r * rowb + lc;
+        stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
     }
-    auto stage = [&](int buf, int jt) {
+    auto stage = [&](int buf, int jt) {  // tiles are staged in order: jt only documents which one this call fetches
         char* sK = smem + buf * 2 * TILEB;
         char* sV = sK + TILEB;
 #pragma unroll
         for (int j = 0; j < SI; ++j) {
-            int key = jt * KT + strow[j];
-            key = key < Ttok ? key : Ttok - 1;  // tail rows re-read the last key; masked below
-            const char* g = base + ((size_t)key * H3 + h * 64) * 2 + stlc[j];
-            glds16(g + (size_t)H * 2, sK + (j * NWV + wid) * 8 * ROWB);
-            glds16(g + (size_t)H * 4, sV + (j * NWV + wid) * 8 * ROWB);
+            const unsigned off = stoff[j] < stmax[j] ? stoff[j] : stmax[j];
+            stoff[j] += KT * rowb;
+            glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);
+            glds16(kbase + off + vdelta, sV + (j * NWV + wid) * 8 * ROWB);
         }
     };
 
@@ -119,7 +177,9 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
     const int ntiles = (Ttok + KT - 1) / KT;
     auto tile = [&](int jt, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
+        DINO_TS(0)
         __syncthreads();
+        DINO_TS(1)
         if (!MASKED) stage((jt + 1) & 1, jt + 1);
         const char* sK = smem + (jt & 1) * 2 * TILEB;
         const char* sV = sK + TILEB;
@@ -134,6 +194,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
                 s[kb] = E::mfma32(kf, qf[ks], ks == 0 ? negm : s[kb]);
             }
         }
+        DINO_TS(2)
         // s[kb][r] = score - m_run of key jt*64 + kb*32 + (r&3) + 8*(r>>2) + 4*hh; only the last tile has keys >= Ttok
         if constexpr (MASKED) {
             const int kbase = jt * KT + 4 * hh;
@@ -144,12 +205,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
                     if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= Ttok) s[kb][r] = -INFINITY;
         }
         // ---- online softmax (soft_max_ext semantics: exp(s - max) / sum), statistics per lane = per query ----
-        float mx = s[0][0];
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));  // tile maximum relative to m_run
+        const float mx = max_halves(max32(s));  // tile maximum relative to m_run
         const bool first = jt == 0;          // m_run = 0 is not a real reference yet: take the tile maximum, whatever it is
         const bool need = first || mx > THR;
         if (__any(need)) {  // wave-uniform; lanes that do not need it shift by d = 0 (alpha = 1)
@@ -166,6 +222,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
                 s[1][r] -= d;
             }
         }
+        DINO_TS(3)
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
@@ -176,6 +233,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
                 psum += pv;
             }
         l_run += psum;
+        DINO_TS(4)
         // ---- O^T += V^T P^T : 4 k-steps of 16 keys; lane's 8 k-slots of step t = score regs (t&1)*8 .. +7 of
         //      block t>>1, i.e. keys 16t + 4hh + {0..3} and 16t + 8 + 4hh + {0..3}
 #pragma unroll
@@ -199,10 +257,12 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
                 o[db] = E::mfma32(vf, pf, o[db]);
             }
         }
+        DINO_TS(5)
     };
     stage(0, 0);
     for (int jt = 0; jt + 1 < ntiles; ++jt) tile(jt, std::false_type{});
     tile(ntiles - 1, std::true_type{});
+    DINO_TS_FLUSH
 
     // ---- normalise and store: o[db][r] = O[q][d], d = db*32 + (r&3) + 8*(r>>2) + 4*hh ----
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -221,8 +281,348 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// attention2: the same mapping, software-pipelined inside each wave.  Measured on attention_kernel: per 64-key tile a wave
+// issues 512 cycles of MFMA and ~600 cycles of VALU (32 v_exp, max, sum, convert) strictly one after the other -- S MFMAs ->
+// max -> exp -> PV MFMAs is one dependency chain -- so each pipe idles while the other works (MFMA busy 40 %).  Here the
+// chain is cut in two: while the softmax of tile j runs on the VALU, the matrix core computes the scores of tile j+1
+// (independent work), and the maximum of tile j+1 is taken under the PV MFMAs of tile j.  K is therefore staged one tile
+// further ahead than V.  The instruction order is written out in groups (one MFMA + its share of VALU + the LDS reads for
+// later groups) and pinned with sched_barrier, so that hipcc neither clusters the MFMAs nor sinks the reads to their uses.
+#define DINO_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef DINO_ATT_ABL
+#define DINO_ATT_ABL 0  // timing-only ablations (WRONG results): 1 no exp, 2 no staging, 4 no barrier, 8 no V reads, 16 no K reads
+#endif
+#ifndef DINO_ATT_LSUM
+#define DINO_ATT_LSUM 1  // softmax denominators on the matrix core: l += ones x P^T, one extra 32x32x16 MFMA per 16 keys
+#endif
+template <typename T, bool LOG2>
+__global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
+    using E = Elem<T>;
+    using vec8 = typename E::vec8;
+    using vec4 = typename E::vec4;
+    constexpr int KT = 64, ROWB = 128, TILEB = KT * ROWB;
+    constexpr bool LSUM = DINO_ATT_LSUM != 0;
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEB];  // [buf][K|V]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    DINO_TS_INIT
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nqb = (Ttok + 127) / 128, nhd = H >> 6;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);  // all query blocks of a head on one XCD (see attention_kernel)
+    const int qb = lid % nqb, h = (lid / nqb) % nhd, b = lid / (nqb * nhd);
+    const int H3 = 3 * H;
+    const char* base = (const char*)(qkv + (size_t)b * Ttok * H3);
+    const int ql = lane & 31, hh = lane >> 5;
+    const int qrow = qb * 128 + wid * 32 + ql;
+    const int qrc = qrow < Ttok ? qrow : Ttok - 1;
+
+    vec8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(base + ((size_t)qrc * H3 + h * 64 + ks * 16 + hh * 8) * 2);
+
+    // staging offsets as in attention_kernel; K runs one tile ahead of V, so each has its own cursor
+    const char* kbase = base + ((size_t)h * 64 + H) * 2;
+    const unsigned rowb = (unsigned)H3 * 2u, vdelta = (unsigned)H * 2u;
+    unsigned koff[2], voff[2], stmax[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (j * 4 + wid) * 8 + (lane >> 3);
+        const unsigned lc = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
+        koff[j] = voff[j] = (unsigned)r * rowb + lc;
+        stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
+    }
+    auto stage_k1 = [&](int buf, int j) {
+        glds16(kbase + (koff[j] < stmax[j] ? koff[j] : stmax[j]), smem + buf * 2 * TILEB + (j * 4 + wid) * 8 * ROWB);
+        koff[j] += KT * rowb;
+    };
+    auto stage_v1 = [&](int buf, int j) {
+        glds16(kbase + (voff[j] < stmax[j] ? voff[j] : stmax[j]) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * 4 + wid) * 8 * ROWB);
+        voff[j] += KT * rowb;
+    };
+    auto stage_k = [&](int buf) { stage_k1(buf, 0); stage_k1(buf, 1); };
+    auto stage_v = [&](int buf) { stage_v1(buf, 0); stage_v1(buf, 1); };
+
+    const int sw = (ql >> 1) & 7;
+    int kaddr[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kaddr[ks] = ql * ROWB + (((ks * 2 + hh) ^ sw) << 4);
+    const int t16 = lane & 15;
+    int vaddr[2][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+            const int row0 = 8 * half + 4 * hh + (t16 >> 2);
+            const int colbyte = db * 64 + (((lane >> 4) & 1) * 16 + (t16 & 3) * 4) * 2;
+            vaddr[half][db] = row0 * ROWB + ((((colbyte >> 4) ^ ((row0 >> 1) & 7)) << 4) | (colbyte & 15));
+        }
+    auto read_vt = [&](const char* sV, int t, int db) {
+        vec8 vf;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const s16x4 raw =
+                __builtin_amdgcn_ds_read_tr16_b64_v4i16((DINO_LDS_AS s16x4*)(sV + vaddr[half][db] + t * 16 * ROWB));
+            const vec4 v4 = __builtin_bit_cast(vec4, raw);
+            vf[half * 4 + 0] = v4[0];
+            vf[half * 4 + 1] = v4[1];
+            vf[half * 4 + 2] = v4[2];
+            vf[half * 4 + 3] = v4[3];
+        }
+        return vf;
+    };
+    auto ex2 = [](float x) { return (DINO_ATT_ABL & 1) ? x * 0.5f : LOG2 ? __builtin_amdgcn_exp2f(x) : __expf(x); };
+
+    f32x16 o[2], negm, lacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = negm[r] = lacc[r] = 0.f;
+    vec8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = E::from_f32(1.0f);
+    float m_run = 0.f, l_run = 0.f;
+    constexpr float THR = LOG2 ? 8.0f : 5.5f;
+    const int ntiles = (Ttok + KT - 1) / KT;
+
+    auto mask_tail = [&](f32x16(&s)[2], int jt) {
+        const int kbase_ = jt * KT + 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase_ + kb * 32 + (r & 3) + 8 * (r >> 2) >= Ttok) s[kb][r] = -INFINITY;
+    };
+    // move the softmax reference point when the tile maximum (relative to it) exceeds THR; `s` holds scores - m_run
+    auto rescale = [&](f32x16(&s)[2], float mx, bool first) {
+        const bool need = first || mx > THR;
+        if (__any(need)) {
+            const float d = need ? mx : 0.f;
+            const float alpha = first ? 0.f : ex2(-d);
+            m_run += d;
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o[0][r] *= alpha;
+                o[1][r] *= alpha;
+                if (LSUM) lacc[r] *= alpha;
+                negm[r] = -m_run;
+                s[0][r] -= d;
+                s[1][r] -= d;
+            }
+        }
+    };
+
+    // one steady-state step: softmax(cur = tile jt) + PV(tile jt), scores of tile jt+1 into nxt.  PAR = jt & 1 (compile
+    // time: LDS offsets become immediates).  All LDS reads of the step are inline asm with hand-counted lgkmcnt: hipcc puts
+    // `s_waitcnt vmcnt(0)` in front of a ds_read that follows an LDS-DMA (it cannot see that the buffers differ), which
+    // would park the wave on the loads it has just issued.  DS returns are in order, so each wait names how many younger
+    // reads may still be outstanding.  Issue order: K0..K3 | group g < 4: K(g+4), V(2g), V(2g+1) | group g >= 4: V(2g), V(2g+1).
+    // Before score MFMA g < 4: (3 - g) + 3g younger reads; g >= 4: 2 + the three groups in between = 11, 10, 9, 8.
+    // PV MFMA u (V fragment u, read in group u) runs in group u + 4 for u < 4 (three groups in between: 9, 8, 7, 6 younger
+    // reads) and after the groups for u >= 4 (2 * (7 - u)).
+    const unsigned lds0 = (unsigned)(uintptr_t)(DINO_LDS_AS char*)smem;
+    unsigned kad[4], vad[2][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) kad[i] = lds0 + kaddr[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vad[i >> 1][i & 1] = lds0 + vaddr[i >> 1][i & 1];
+#define DINO_KRD(DST, ADDR, OFF) \
+    if (!(DINO_ATT_ABL & 16)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define DINO_VRD(DST, ADDR, OFF) \
+    if (!(DINO_ATT_ABL & 8)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+    auto iter = [&](int jt, f32x16(&cur)[2], f32x16(&nxt)[2], auto mask_tag, auto par_tag) {
+        constexpr bool MASKNEXT = decltype(mask_tag)::value;
+        constexpr int PAR = decltype(par_tag)::value;
+        constexpr int KOFF = ((PAR + 1) & 1) * 2 * TILEB;  // K_{jt+1}
+        constexpr int VOFF = PAR * 2 * TILEB + TILEB;      // V_jt
+        DINO_TS(0)
+        if (!(DINO_ATT_ABL & 4)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // K_{jt+1}, V_jt landed (staged one step ago); buffers of K_jt, V_{jt-1} are free
+        }
+        DINO_TS(1)
+        vec8 kf[8], pf[4];
+        s16x4 vl[8], vh[8];
+        if (DINO_ATT_ABL & 24) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                kf[i] = qf[i & 3];
+                vl[i] = vh[i] = __builtin_bit_cast(s16x4, (double)jt);
+            }
+        }
+        DINO_KRD(kf[0], kad[0], KOFF);
+        DINO_KRD(kf[1], kad[1], KOFF);
+        DINO_KRD(kf[2], kad[2], KOFF);
+        DINO_KRD(kf[3], kad[3], KOFF);
+        DINO_SB();
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#define DINO_PVMMA(U, WAITN)                                                                                 \
+        {                                                                                                    \
+            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vl[U]), "+v"(vh[U]) : "n"(WAITN));                   \
+            const vec4 lo = __builtin_bit_cast(vec4, vl[U]), hi = __builtin_bit_cast(vec4, vh[U]);           \
+            const vec8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                         \
+            o[(U) & 1] = E::mfma32(vf, pf[(U) >> 1], o[(U) & 1]);                                            \
+        }
+#define DINO_GROUP(G)                                                                                        \
+        {                                                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+                const int idx = (G) * 4 + j;                                                                 \
+                const float pv = ex2(cur[idx >> 4][idx & 15]);                                               \
+                cur[idx >> 4][idx & 15] = pv;                                                                \
+                if (!LSUM) ps[j] += pv;                                                                      \
+            }                                                                                                \
+            DINO_SB();                                                                                       \
+            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kf[G]) : "n"((G) < 4 ? 3 + 2 * (G) : 15 - (G)));     \
+            nxt[(G) >> 2] = E::mfma32(kf[G], qf[(G) & 3], ((G) & 3) == 0 ? negm : nxt[(G) >> 2]);            \
+            if ((G) & 1) {                                                                                   \
+                _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                \
+                    pf[(G) >> 1][j] = E::from_f32(cur[(G) >> 2][(((G) >> 1) & 1) * 8 + j]);                  \
+                if (LSUM) lacc = E::mfma32(ones, pf[(G) >> 1], lacc);                                        \
+            }                                                                                                \
+            if ((G) >= 4) DINO_PVMMA(((G) - 4) & 7, 13 - (G))                                                \
+            if (!(DINO_ATT_ABL & 2)) {                                                                       \
+                if ((G) == 0) stage_k1(PAR, 0);            /* K_{jt+2}: the loads go out under the MFMAs */   \
+                if ((G) == 1) stage_k1(PAR, 1);                                                              \
+                if ((G) == 2) stage_v1((PAR + 1) & 1, 0);  /* V_{jt+1} */                                    \
+                if ((G) == 3) stage_v1((PAR + 1) & 1, 1);                                                    \
+            }                                                                                                \
+            if ((G) < 4) DINO_KRD(kf[((G) + 4) & 7], kad[(G) & 3], KOFF + 4096);                             \
+            DINO_VRD(vl[G], vad[0][(G) & 1], VOFF + ((G) >> 1) * 16 * ROWB);                                 \
+            DINO_VRD(vh[G], vad[1][(G) & 1], VOFF + ((G) >> 1) * 16 * ROWB);                                 \
+            DINO_SB();                                                                                       \
+        }
+        DINO_GROUP(0) DINO_GROUP(1) DINO_GROUP(2) DINO_GROUP(3) DINO_GROUP(4) DINO_GROUP(5) DINO_GROUP(6) DINO_GROUP(7)
+#undef DINO_GROUP
+        if (!LSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        DINO_TS(2)
+        if constexpr (MASKNEXT) mask_tail(nxt, jt + 1);
+        // second half of PV (keys 32..63 of the tile) with the maximum of the next tile's scores underneath
+        float ma, mb;
+#define DINO_PV(U)                                                                                           \
+        {                                                                                                    \
+            DINO_PVMMA(U, 14 - 2 * (U))                                                                      \
+            _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                  \
+                const f32x16& n = nxt[((U) - 4) >> 1];                                                       \
+                const int i0 = (((U) - 4) & 1) * 8 + c * 4;                                                  \
+                ma = ((U) == 4 && c == 0) ? max3f(n[0], n[0], n[1]) : max3f(ma, n[i0], n[i0 + 1]);           \
+                mb = ((U) == 4 && c == 0) ? max3f(n[2], n[2], n[3]) : max3f(mb, n[i0 + 2], n[i0 + 3]);       \
+            }                                                                                                \
+            DINO_SB();                                                                                       \
+        }
+        DINO_PV(4) DINO_PV(5) DINO_PV(6) DINO_PV(7)
+#undef DINO_PV
+#undef DINO_PVMMA
+        DINO_TS(3)
+        rescale(nxt, max_halves(max3f(ma, mb, mb)), false);
+        DINO_TS(4)
+    };
+    auto last = [&](int jt, f32x16(&cur)[2]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* sV = smem + (jt & 1) * 2 * TILEB + TILEB;
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            vec8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = ex2(cur[t >> 1][(t & 1) * 8 + j]);
+                ps[j & 3] += pv;
+                pf[j] = E::from_f32(pv);
+            }
+            if (LSUM) lacc = E::mfma32(ones, pf, lacc);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) o[db] = E::mfma32(read_vt(sV, t, db), pf, o[db]);
+        }
+        if (!LSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    };
+
+    // prologue: K_0, V_0, K_1 in flight; scores of tile 0
+    stage_k(0);
+    stage_v(0);
+    stage_k(1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 sa[2], sb[2];
+    {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                sa[kb] = E::mfma32(*(const vec8*)(smem + kaddr[ks] + kb * 32 * ROWB), qf[ks], ks == 0 ? negm : sa[kb]);
+        if (ntiles == 1) mask_tail(sa, 0);
+        rescale(sa, max_halves(max32(sa)), true);
+    }
+    // steps jt = 0 .. ntiles-2 (the last of them masks the tail of its next tile), two per trip so that the score
+    // registers swap roles without moves
+    DINO_TS(5)
+    int jt = 0;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    for (; jt + 2 < ntiles - 1; jt += 2) {
+        iter(jt, sa, sb, std::false_type{}, P0{});
+        iter(jt + 1, sb, sa, std::false_type{}, P1{});
+    }
+    if (jt + 2 == ntiles - 1) {  // two steps left
+        iter(jt, sa, sb, std::false_type{}, P0{});
+        iter(jt + 1, sb, sa, std::true_type{}, P1{});
+        last(ntiles - 1, sa);
+    } else if (jt + 1 == ntiles - 1) {  // one step left
+        iter(jt, sa, sb, std::true_type{}, P0{});
+        last(ntiles - 1, sb);
+    } else {
+        last(ntiles - 1, sa);  // ntiles == 1
+    }
+
+    DINO_TS(6)
+    DINO_TS_FLUSH
+    // with LSUM every element of lacc is the full row sum (both lane halves included)
+    const float l_tot = LSUM ? lacc[0] : l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    if (qrow < Ttok) {
+        T* orow = out + ((size_t)b * Ttok + qrow) * H + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                vec4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = E::from_f32(o[db][g * 4 + j] * inv);
+                *(vec4*)(orow + db * 32 + g * 8 + hh * 4) = w;
+            }
+    }
+}
+#undef DINO_KRD
+#undef DINO_VRD
+
+#ifdef DINO_ATT_PROF
+static void att_prof_dump(int nwaves) {
+    static std::vector<unsigned long long> h(32768 * 8);
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_att_prof), h.size() * 8);
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int n = nwaves < 32768 ? nwaves : 32768;
+    for (int w = 0; w < n; ++w)
+        for (int i = 0; i < 8; ++i) acc[i] += (double)h[w * 8 + i];
+    fprintf(stderr, "att_prof cycles/wave:");
+    for (int i = 0; i < 8; ++i) fprintf(stderr, " [%d] %.0f", i, acc[i] / n);
+    fprintf(stderr, "\n");
+}
+#endif
+
+static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
+                                        hipStream_t st);
 hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
                             hipStream_t st) {
+    const hipError_t e = launch_attention_impl(dt, qkv, out, B, T, H, nh, log2_scores, st);
+#ifdef DINO_ATT_PROF
+    att_prof_dump(B * nh * ((T + 127) / 128) * 4);
+#endif
+    return e;
+}
+
+static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
+                                        hipStream_t st) {
     if (H != nh * 64 || T <= 0 || B <= 0) return hipErrorInvalidValue;
     // 8 waves (256 queries) per workgroup halve the K/V staging per query; 4 waves waste less on the ragged last query
     // block.  DINOV2_HIP_ATTN_WAVES=4|8 overrides (tuning aid).
@@ -231,7 +631,19 @@ hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, 
         return e ? atoi(e) : 0;
     }();
     const int nwv = forced == 4 || forced == 8 ? forced : 4;  // A/B on MI355X: equal within noise (0.41-0.43 ms)
-    const dim3 grid((T + nwv * 32 - 1) / (nwv * 32), nh, B), block(nwv * 64);
+    static const int ver = [] {
+        const char* e = getenv("DINOV2_HIP_ATTN_V");
+        return e ? atoi(e) : 1;  // A/B on MI355X (warm clocks): attention_kernel 0.296 ms, attention2 0.31-0.32
+    }();
+    if (ver == 2 && !forced) {
+        const dim3 grid2(((T + 127) / 128) * nh * B), block2(256);
+#define DINO_ATT2(TT, LG) hipLaunchKernelGGL((attention2_kernel<TT, LG>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H)
+        if (dt == DT_F16) { if (log2_scores) DINO_ATT2(_Float16, true); else DINO_ATT2(_Float16, false); }
+        else { if (log2_scores) DINO_ATT2(__bf16, true); else DINO_ATT2(__bf16, false); }
+#undef DINO_ATT2
+        return hipGetLastError();
+    }
+    const dim3 grid(((T + nwv * 32 - 1) / (nwv * 32)) * nh * B), block(nwv * 64);
 #define DINO_ATT(TT, LG, NW) \
     hipLaunchKernelGGL((attention_kernel<TT, LG, NW>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
     if (dt == DT_F16) {

@@ -1,5 +1,6 @@
 // Diagnostic entry points (include/dinov2_hip_ops.h): run ONE kernel on host-provided f32 data so that the parity
 // tests can check each hand-written kernel against the oracle / numpy in isolation.  Not used by predict.
+#include <chrono>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -200,7 +201,10 @@ extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);
+    for (auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(100);) {
+        for (int i = 0; i < 10; ++i) (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);  // ~100 ms warm-up (clock ramp)
+        (void)hipDeviceSynchronize();
+    }
     if (getenv("DINOV2_HIP_GEMM_TS")) {  // tuning aid: print s_memtime phase stamps of block 0 / wave 0
         DevBuf dT;
         if (dT.alloc(64 * 8) == hipSuccess) {
@@ -236,7 +240,11 @@ extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
-    for (int i = 0; i < 3; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, true, nullptr);
+    // warm up for ~100 ms: a cold GPU runs the first milliseconds at a fraction of its sustained clock
+    for (auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(100);) {
+        for (int i = 0; i < 10; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, true, nullptr);
+        (void)hipDeviceSynchronize();
+    }
     (void)hipEventRecord(e0, nullptr);
     for (int i = 0; i < iters; ++i) (void)launch_attention(dt, dQ.p, dO.p, B, T, H, nh, true, nullptr);
     (void)hipEventRecord(e1, nullptr);

@@ -150,7 +150,7 @@ def _attn_ref(qkv, B, T, H, nh, dt):
 
 
 @pytest.mark.parametrize("dt", [F16, BF16])
-@pytest.mark.parametrize("B,T,nh", [(2, 200, 2), (1, 1374, 1), (1, 64, 3), (1, 37, 1), (2, 129, 2)])
+@pytest.mark.parametrize("B,T,nh", [(2, 200, 2), (1, 1374, 1), (1, 64, 3), (1, 37, 1), (2, 129, 2), (1, 100, 1), (1, 450, 2), (1, 513, 1)])
 def test_attention(api, dt, B, T, nh):
     """soft_max_ext(K^T Q) V per head; T not a multiple of 64 exercises the masked key tail, T % 128 the query tail."""
     H = nh * 64

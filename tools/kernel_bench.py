@@ -18,7 +18,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--hidden", type=int, default=1024)
 ap.add_argument("--ffn", type=int, default=4096)
 ap.add_argument("--tokens", type=int, default=1374)
-ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--dtype", type=int, default=0)
 ap.add_argument("--only", default="")
 ap.add_argument("--shape", action="append", default=[], help="name,epi,M,N,K (repeatable): custom GEMM shapes")
