@@ -252,6 +252,10 @@ hipError_t gemm2_init();
 hipError_t gemm_init() {
     hipError_t e = set_attr_cfg<_Float16, 128, 128, 2, 2>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 128, 128, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 64, 2, 1>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 64, 2, 1>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -273,6 +277,18 @@ static bool use_big_tile(const GemmArgs& a) {
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (epi != EPI_PATCH && use_big_tile(a)) return launch_gemm2(dt, epi, a, st);
+    // small problems (batch 1: M = 1374): 128x128 tiles leave most CUs idle and one workgroup per CU cannot hide the
+    // global -> LDS latency of its K loop; smaller tiles give more, co-resident workgroups.  DINOV2_HIP_GEMM_SMALL=0|1|2 forces.
+    static const int forced_small = [] {
+        const char* e = getenv("DINOV2_HIP_GEMM_SMALL");
+        return e ? atoi(e) : -1;
+    }();
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    int cfg = t128 >= 512 ? 0 : t128 >= 192 ? 1 : 2;
+    if (epi == EPI_SWIGLU && cfg == 2) cfg = 1;
+    if (forced_small >= 0) cfg = forced_small;
+    if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2>(epi, a, st);
+    if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 64, 2, 1>(epi, a, st) : launch_cfg<__bf16, 64, 64, 2, 1>(epi, a, st);
     return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2>(epi, a, st);
 }
 
