@@ -59,6 +59,13 @@ static __device__ __forceinline__ float max_halves(float m) {
     asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "+v"(b));
     return max3f(a, b, b);
 }
+// hipcc's hazard recogniser pads an MFMA result -> VALU read with the required wait states only when it can see the reader;
+// the asm v_max3 below is opaque to it, so reading fresh accumulators raced with the matrix pipeline (nondeterministic
+// scores, found by the batch-permutation test).  19 wait states cover a 16-pass MFMA; tied operands order the block after
+// the MFMAs and before the readers.
+static __device__ __forceinline__ void mfma_settle(f32x16 (&s)[2]) {
+    asm volatile("s_nop 15\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
+}
 // maximum of the 32 scores a lane holds: 16 v_max3 in four independent chains + 2 to join them
 static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
     float m0 = max3f(s[0][0], s[0][1], s[0][2]), m1 = max3f(s[0][3], s[0][4], s[0][5]);
@@ -80,7 +87,7 @@ static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
 // multiply.  launch_bounds(256, 2): allow up to 256 VGPRs -- with the default budget hipcc parked 128 values in AGPRs
 // and spent 255 v_accvgpr moves per key tile shuttling them (as many VALU ops as the softmax itself).
 template <typename T, bool LOG2, int NWV>
-__global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
+__global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
@@ -205,6 +212,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 4 ? 2 : 4) void attention_kernel(c
                     if (kbase + kb * 32 + (r & 3) + 8 * (r >> 2) >= Ttok) s[kb][r] = -INFINITY;
         }
         // ---- online softmax (soft_max_ext semantics: exp(s - max) / sum), statistics per lane = per query ----
+        mfma_settle(s);
         const float mx = max_halves(max32(s));  // tile maximum relative to m_run
         const bool first = jt == 0;          // m_run = 0 is not a real reference yet: take the tile maximum, whatever it is
         const bool need = first || mx > THR;
@@ -497,6 +505,7 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
         DINO_TS(2)
         if constexpr (MASKNEXT) mask_tail(nxt, jt + 1);
         // second half of PV (keys 32..63 of the tile) with the maximum of the next tile's scores underneath
+        mfma_settle(nxt);
         float ma, mb;
 #define DINO_PV(U)                                                                                           \
         {                                                                                                    \
@@ -551,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
             for (int ks = 0; ks < 4; ++ks)
                 sa[kb] = E::mfma32(*(const vec8*)(smem + kaddr[ks] + kb * 32 * ROWB), qf[ks], ks == 0 ? negm : sa[kb]);
         if (ntiles == 1) mask_tail(sa, 0);
+        mfma_settle(sa);
         rescale(sa, max_halves(max32(sa)), true);
     }
     // steps jt = 0 .. ntiles-2 (the last of them masks the tail of its next tile), two per trip so that the score
@@ -630,7 +640,8 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
         const char* e = getenv("DINOV2_HIP_ATTN_WAVES");
         return e ? atoi(e) : 0;
     }();
-    const int nwv = forced == 4 || forced == 8 ? forced : 4;  // A/B on MI355X: equal within noise (0.41-0.43 ms)
+    // (64-query workgroups, DINOV2_HIP_ATTN_WAVES=2, double the workgroup count at batch 1 but measured slower: 28 vs 25 us)
+    const int nwv = forced == 2 || forced == 4 || forced == 8 ? forced : 4;
     static const int ver = [] {
         const char* e = getenv("DINOV2_HIP_ATTN_V");
         return e ? atoi(e) : 1;  // A/B on MI355X (warm clocks): attention_kernel 0.296 ms, attention2 0.31-0.32
@@ -646,13 +657,11 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     const dim3 grid(((T + nwv * 32 - 1) / (nwv * 32)) * nh * B), block(nwv * 64);
 #define DINO_ATT(TT, LG, NW) \
     hipLaunchKernelGGL((attention_kernel<TT, LG, NW>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
-    if (dt == DT_F16) {
-        if (nwv == 8) { if (log2_scores) DINO_ATT(_Float16, true, 8); else DINO_ATT(_Float16, false, 8); }
-        else { if (log2_scores) DINO_ATT(_Float16, true, 4); else DINO_ATT(_Float16, false, 4); }
-    } else {
-        if (nwv == 8) { if (log2_scores) DINO_ATT(__bf16, true, 8); else DINO_ATT(__bf16, false, 8); }
-        else { if (log2_scores) DINO_ATT(__bf16, true, 4); else DINO_ATT(__bf16, false, 4); }
-    }
+#define DINO_ATT_N(TT, LG) \
+    { if (nwv == 8) DINO_ATT(TT, LG, 8); else if (nwv == 2) DINO_ATT(TT, LG, 2); else DINO_ATT(TT, LG, 4); }
+    if (dt == DT_F16) { if (log2_scores) DINO_ATT_N(_Float16, true) else DINO_ATT_N(_Float16, false) }
+    else { if (log2_scores) DINO_ATT_N(__bf16, true) else DINO_ATT_N(__bf16, false) }
+#undef DINO_ATT_N
 #undef DINO_ATT
     return hipGetLastError();
 }

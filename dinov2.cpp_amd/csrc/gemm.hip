@@ -28,7 +28,7 @@
 
 namespace dinov2 {
 
-template <typename T, int BM, int BN, int WM, int WN, int EPI>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma clang fp contract(off)  // position-independent results: see gemm2.hip
     using E = Elem<T>;
@@ -100,14 +100,28 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // NST-stage LDS ring, tiles kt+1 .. kt+NST-1 in flight while tile kt is multiplied: with few workgroups per CU (small M)
+    // nothing else hides the global -> LDS latency.  One barrier per K tile: (a) every wave's loads of tile kt have landed
+    // (each wave waits for its own with a counted vmcnt -- loads return in order -- before the barrier), (b) every wave is
+    // done reading the buffer that tile kt+NST-1 is about to overwrite.  Raw s_barrier: __syncthreads() would drain vmcnt.
+    constexpr int LPT = AI + BI;  // glds instructions per wave per tile
+    static_assert((NST - 2) * LPT < 64, "vmcnt is 6 bits");
     const int nk = K / BK;
-    stage(0, 0);
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) stage(t, t);
+    int buf = 0, nbuf = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        // one barrier per K tile: (a) every wave's loads of tile kt have landed (vmcnt(0) precedes the barrier),
-        // (b) every wave is done reading the buffer tile kt+1 is about to overwrite
-        __syncthreads();
-        if (kt + 1 < nk && !(DINO_GEMM_DBG & 2)) stage((kt + 1) & 1, kt + 1);
-        const char* s = smem + (kt & 1) * STAGE;
+        const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;  // younger tiles that may still be in flight
+        if (NST == 2 || ahead == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPT < 64 ? 2 * LPT : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPT < 64 ? 3 * LPT : 0) : "memory");
+        static_assert(NST <= 5, "extend the vmcnt dispatch above");
+        if (kt + NST - 1 < nk && !(DINO_GEMM_DBG & 2)) stage(nbuf, kt + NST - 1);
+        const char* s = smem + buf * STAGE;
+        nbuf = buf;  // the buffer just consumed is the next to be refilled
+        buf = buf + 1 == NST ? 0 : buf + 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ch = ((ks * 2 + fh) ^ sw) << 4;
@@ -207,14 +221,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NST>
 static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
     const dim3 grid(ntn * ntm), block(WM * WN * 64);
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    const size_t lds = NST * (size_t)(BM + BN) * 128;
 #define DINO_LAUNCH(E)                                                                             \
     case E:                                                                                        \
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, E>), grid, block, lds, st, a);         \
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E>), grid, block, lds, st, a);         \
         break;
     switch (epi) {
         DINO_LAUNCH(EPI_PATCH)
@@ -228,13 +242,13 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int WM, int WN>
+template <typename T, int BM, int BN, int WM, int WN, int NST>
 static hipError_t set_attr_cfg() {
-    const int lds = 2 * (BM + BN) * 128;
+    const int lds = NST * (BM + BN) * 128;
     hipError_t e = hipSuccess;
 #define DINO_ATTR(E)                                                                                          \
     if (e == hipSuccess)                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, E>),            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E>),            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DINO_ATTR(EPI_PATCH)
     DINO_ATTR(EPI_QKV)
@@ -250,12 +264,12 @@ hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t s
 hipError_t gemm2_init();
 
 hipError_t gemm_init() {
-    hipError_t e = set_attr_cfg<_Float16, 128, 128, 2, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 128, 128, 2, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 64, 2, 1>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 64, 2, 1>();
+    hipError_t e = set_attr_cfg<_Float16, 128, 128, 2, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 128, 128, 2, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 3>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -278,18 +292,21 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (epi != EPI_PATCH && use_big_tile(a)) return launch_gemm2(dt, epi, a, st);
     // small problems (batch 1: M = 1374): 128x128 tiles leave most CUs idle and one workgroup per CU cannot hide the
-    // global -> LDS latency of its K loop; smaller tiles give more, co-resident workgroups.  DINOV2_HIP_GEMM_SMALL=0|1|2 forces.
+    // global -> LDS latency of its K loop.  64x128 tiles with 2 LDS stages (48 KiB: three workgroups per CU hide each other's
+    // latency) when there are enough tiles, with 3 stages (72 KiB) when there are not (N = 1024 at batch 1: 176 tiles; the
+    // K = 4096 GEMM 39.7 -> 33.8 us).  Measured at M = 1374: 128x128 / 64x128x2 / 64x128x3 = qkv 21.8 / 19.5 / 27.1 us,
+    // ffn-in 31.2 / 24.9 / 34.0, ffn-out 49.0 / 39.7 / 33.8.  DINOV2_HIP_GEMM_SMALL=0|1|2 forces a configuration.
     static const int forced_small = [] {
         const char* e = getenv("DINOV2_HIP_GEMM_SMALL");
         return e ? atoi(e) : -1;
     }();
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    int cfg = t128 >= 512 ? 0 : t128 >= 192 ? 1 : 2;
-    if (epi == EPI_SWIGLU && cfg == 2) cfg = 1;
+    const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    int cfg = t128 >= 512 ? 0 : t64 >= 384 ? 1 : 2;
     if (forced_small >= 0) cfg = forced_small;
-    if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2>(epi, a, st);
-    if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 64, 2, 1>(epi, a, st) : launch_cfg<__bf16, 64, 64, 2, 1>(epi, a, st);
-    return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2>(epi, a, st);
+    if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
+    if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
+    return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2, 2>(epi, a, st);
 }
 
 }  // namespace dinov2

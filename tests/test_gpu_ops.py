@@ -167,6 +167,24 @@ def test_attention(api, dt, B, T, nh):
     np.testing.assert_allclose(out, ref, rtol=tol, atol=tol)
 
 
+def test_attention_bitwise_repeatable(api):
+    """Same input, four runs, identical bits: a softmax statistic read from MFMA accumulators before the matrix pipeline
+    had written them back (an opaque asm reader hides the hazard from the compiler) showed up as run-to-run noise of 2e-4
+    that every tolerance-based comparison passed."""
+    B, T, nh = 2, 1374, 4
+    H = nh * 64
+    rng = np.random.default_rng(77)
+    qkv = _round(rng.standard_normal((B * T, 3 * H)).astype(np.float32) * 0.7, F16)
+    outs = []
+    for _ in range(4):
+        out = np.zeros((B * T, H), np.float32)
+        assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
+        outs.append(out)
+    assert np.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
+
+
 def test_attention_online_softmax_rescale(api):
     """Force the running-max update late in the key sequence: one query gets a spike on a key in the LAST tile."""
     B, T, nh, H = 1, 300, 1, 64
