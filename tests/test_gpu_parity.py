@@ -186,3 +186,42 @@ def test_full_size_large_properties(api, pkg, tmp_path):
     assert np.array_equal(perm["logits"][::-1], got["logits"])
     np.testing.assert_allclose(got["probs"].sum(-1), 1.0, atol=1e-5)
     assert np.isfinite(got["patch_tokens"]).all()
+
+
+@pytest.mark.parametrize("name", ["tiny_gelu_reg4", "tiny_swiglu_reg4"])
+@pytest.mark.parametrize("h,w", [(14, 14), (14, 70), (154, 98), (406, 406)])
+def test_shape_edge_cases(api, golden_dir, name, h, w):
+    """Extremes of the token count: a single patch (T = 6: one partial key tile, one partial query block), a 1 x 5 strip,
+    a non-square 11 x 7 grid, and 29 x 29 = 841 patches (T = 846: 14 key tiles, 7 query blocks, pos-embed upsampled from
+    5 x 5) -- classify and features against the oracle."""
+    gguf = os.path.join(golden_dir, name + ".gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    ora = OracleModel(gguf)
+    img = np.random.default_rng(h * 1000 + w).standard_normal((3, h, w)).astype(np.float32)
+    for classify in (True, False):
+        exp = ora.forward(img, classify=classify)
+        got = sess.predict(img[None], classify=classify)
+        assert got["patch_tokens"].shape[1:] == exp["patch_tokens"].shape
+        assert _rel(got["patch_tokens"][0], exp["patch_tokens"]) <= 5e-3
+        assert _rel(got["cls"][0], exp["cls"]) <= 5e-3
+        if classify:
+            assert _rel(got["logits"][0], exp["logits"]) <= 1e-3
+            np.testing.assert_allclose(got["probs"][0].sum(), 1.0, atol=1e-5)
+
+
+def test_odd_batch_and_session_reuse_across_shapes(api, golden_dir):
+    """Batch 37 (ragged GEMM row tiles, several attention grid rows), then the same session at other shapes and back:
+    the workspace is re-carved and the cached interpolated pos-embed is refreshed each time."""
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    ora = OracleModel(gguf)
+    rng = np.random.default_rng(37)
+    big = rng.standard_normal((37, 3, 70, 70)).astype(np.float32)
+    got = sess.predict(big, classify=True)
+    for b in (0, 17, 36):
+        assert _rel(got["logits"][b], ora.forward(big[b], classify=True)["logits"]) <= 1e-3
+    other = rng.standard_normal((2, 3, 98, 42)).astype(np.float32)
+    g2 = sess.predict(other, classify=True)
+    assert _rel(g2["logits"][1], ora.forward(other[1], classify=True)["logits"]) <= 1e-3
+    again = sess.predict(big, classify=True)
+    assert np.array_equal(again["logits"], got["logits"])
