@@ -231,16 +231,18 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
             }
         }
         DINO_TS(3)
-        float psum = 0.f;
+        // four summation chains (register index mod 4), joined pairwise: the SAME order as attention2_kernel, so that the two
+        // kernels agree bit for bit and an image's result does not depend on which one its batch size selects
+        float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = LOG2 ? __builtin_amdgcn_exp2f(s[kb][r]) : __expf(s[kb][r]);
                 s[kb][r] = pv;
-                psum += pv;
+                ps[r & 3] += pv;
             }
-        l_run += psum;
+        l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         DINO_TS(4)
         // ---- O^T += V^T P^T : 4 k-steps of 16 keys; lane's 8 k-slots of step t = score regs (t&1)*8 .. +7 of
         //      block t>>1, i.e. keys 16t + 4hh + {0..3} and 16t + 8 + 4hh + {0..3}
@@ -302,7 +304,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
 #define DINO_ATT_ABL 0  // timing-only ablations (WRONG results): 1 no exp, 2 no staging, 4 no barrier, 8 no V reads, 16 no K reads
 #endif
 #ifndef DINO_ATT_LSUM
-#define DINO_ATT_LSUM 1  // softmax denominators on the matrix core: l += ones x P^T, one extra 32x32x16 MFMA per 16 keys
+#define DINO_ATT_LSUM 0  // 1: softmax denominators on the matrix core (l += ones x P^T, one extra MFMA per 16 keys).  Sums the
+                        // f16-rounded probabilities, so it is NOT bit-identical to attention_kernel: off by default
 #endif
 template <typename T, bool LOG2>
 __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
@@ -642,10 +645,14 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     }();
     // (64-query workgroups, DINOV2_HIP_ATTN_WAVES=2, double the workgroup count at batch 1 but measured slower: 28 vs 25 us)
     const int nwv = forced == 2 || forced == 4 || forced == 8 ? forced : 4;
-    static const int ver = [] {
-        const char* e = getenv("DINOV2_HIP_ATTN_V");
-        return e ? atoi(e) : 1;  // A/B on MI355X (warm clocks): attention_kernel 0.296 ms, attention2 0.31-0.32
-    }();
+    // Two kernels, chosen by how many workgroups there are per CU.  Many (batch 32: 5 632 on 256 CUs): attention_kernel, 121
+    // VGPRs, four workgroups per CU hide each other's latencies (0.296 ms vs 0.31-0.32).  Few (batch 1: 176): nothing to
+    // overlap with, so the per-wave dependency chain decides and the software-pipelined attention2_kernel wins (22 vs 26 us).
+    // DINOV2_HIP_ATTN_V=1|2 forces one.
+    const char* ev = getenv("DINOV2_HIP_ATTN_V");  // read per launch: tests flip it
+    const int forced_ver = ev ? atoi(ev) : 0;
+    const long units = (long)((T + 127) / 128) * nh * B;
+    const int ver = forced_ver ? forced_ver : units <= 512 ? 2 : 1;
     if (ver == 2 && !forced) {
         const dim3 grid2(((T + 127) / 128) * nh * B), block2(256);
 #define DINO_ATT2(TT, LG) hipLaunchKernelGGL((attention2_kernel<TT, LG>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H)
