@@ -204,14 +204,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                     } else if constexpr (EPI == EPI_RESID) {
                         ((float*)p.out)[(size_t)row * p.ldo + col] = v * auxv + xin[r];
                     } else if constexpr (EPI == EPI_GELU) {
-                        // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))), x<=-10 -> 0, x>=10 -> x
+                        // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))).  EXACTLY the expression of
+                        // gemm2.hip (same constants, same operation order; the x <= -10 / x >= 10 branches fall out of it):
+                        // a token must get the same bits from either kernel, whatever batch it arrives in.
                         const float xr = (float)(_Float16)v;
-                        const float u = 0.79788456080286535587989211986876f * xr * (1.0f + 0.044715f * xr * xr);
-                        float g = xr * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));  // == 0.5 x (1 + tanh u)
+                        const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
+                        float g = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
                         asm volatile("" : "+v"(g));
-                        g = (float)(_Float16)g;
-                        g = v <= -10.0f ? 0.0f : (v >= 10.0f ? v : g);
-                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(g);
+                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32((float)(_Float16)g);
                     } else {  // EPI_PLAIN_F32
                         ((float*)p.out)[(size_t)row * p.ldo + col] = v;
                     }

@@ -314,3 +314,21 @@ def test_gemm_rows_do_not_depend_on_their_position(api, name, epi, N):
     out = np.zeros((3 * T, N), np.float32)
     _gemm(api, F16, epi, A, W, bias, aux, out, 3 * T, N, K, N, qcols=N // 3, qscale=0.125)
     assert np.array_equal(out[:T], out[2 * T:])
+
+
+@pytest.mark.parametrize("name,epi,N,K", [("qkv", EPI_QKV, 3072, 1024), ("gelu", EPI_GELU, 4096, 1024), ("resid", EPI_RESID, 1024, 1024),
+                                          ("resid_k4096", EPI_RESID, 1024, 4096)])
+def test_gemm_small_and_large_m_agree_bit_for_bit(api, name, epi, N, K):
+    """One image (M = 1374: 64x128 tiles, 2- or 3-stage ring) against the same rows inside a batch of 32 (M = 43968: the
+    persistent 256x256 kernel): identical bits, so a token's result does not depend on the batch it arrives in."""
+    rng = np.random.default_rng(11)
+    T = 1374
+    X = _round(rng.standard_normal((T, K)), F16)
+    W = _round(rng.standard_normal((N, K)) * 0.05, F16)
+    bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    x0 = rng.standard_normal((T, N)).astype(np.float32) if epi == EPI_RESID else np.zeros((T, N), np.float32)
+    small = x0.copy()
+    _gemm(api, F16, epi, X, W, bias, aux, small, T, N, K, N, qcols=N // 3, qscale=0.125)
+    big = np.ascontiguousarray(np.tile(x0, (32, 1)))
+    _gemm(api, F16, epi, np.ascontiguousarray(np.tile(X, (32, 1))), W, bias, aux, big, 32 * T, N, K, N, qcols=N // 3, qscale=0.125)
+    assert np.array_equal(big[:T], small) and np.array_equal(big[-T:], small)

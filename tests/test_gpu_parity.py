@@ -225,3 +225,17 @@ def test_odd_batch_and_session_reuse_across_shapes(api, golden_dir):
     assert _rel(g2["logits"][1], ora.forward(other[1], classify=True)["logits"]) <= 1e-3
     again = sess.predict(big, classify=True)
     assert np.array_equal(again["logits"], got["logits"])
+
+
+def test_image_result_independent_of_batch_size(api, pkg, tmp_path):
+    """ViT-L/14 shapes (4 layers): an image alone (batch 1: 64x128-tile GEMMs, pipelined attention kernel) and the same image
+    inside a batch of 24 (persistent 256x256 GEMM, high-occupancy attention kernel) give identical bits."""
+    path = str(tmp_path / "large4b.gguf")
+    pkg.synth.write_synthetic_gguf(path, "large", registers=4, num_classes=1000, seed=7, layers=4)
+    imgs = pkg.synth.synthetic_images(24, 518, 518, seed=7)
+    sess = api.Session(api.Model(path, classify=True))
+    full = sess.predict(imgs, classify=True)
+    for b in (0, 23):
+        one = sess.predict(imgs[b:b + 1], classify=True)
+        assert np.array_equal(one["logits"][0], full["logits"][b])
+        assert np.array_equal(one["patch_tokens"][0], full["patch_tokens"][b])
