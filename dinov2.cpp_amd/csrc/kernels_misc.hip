@@ -1,10 +1,37 @@
 // kernels_misc.hip -- the HBM-bound kernels around the GEMMs: LayerNorm, im2col, token init, load-time weight
 // conversion / dequantisation, classifier head.  All are wavefront (64-lane) designs with 16-byte accesses.
+#include <type_traits>
+
 #include "device_types.h"
 #include "gguf_reader.h"
 #include "kernels.h"
 
 namespace dinov2 {
+
+// Sum of a double over the 64 lanes of a wave, result in every lane.  DPP moves on the two 32-bit halves (quad swaps, half-row
+// and row mirrors, then one readlane per 16-lane row) instead of six ds_bpermute round trips through the LDS pipe: the
+// LayerNorm is two such reductions per row, and at batch 1 their latency was a third of the kernel.
+static __device__ __forceinline__ double wave_sum_f64(double v) {
+    auto dpp = [](double x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+        const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)u, C, 0xF, 0xF, false);
+        const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(u >> 32), C, 0xF, 0xF, false);
+        return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: every lane of a 16-lane row holds the row's sum
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    double r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned lo = __builtin_amdgcn_readlane((unsigned)u, 16 * i), hi = __builtin_amdgcn_readlane((unsigned)(u >> 32), 16 * i);
+        r[i] = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    return (r[0] + r[1]) + (r[2] + r[3]);
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm: ggml_norm + mul + add  (/root/reference/dinov2.cpp:694-700, 722-728, 756-760)
@@ -30,8 +57,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             sum += (double)v[j].x + (double)v[j].y + (double)v[j].z + (double)v[j].w;
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    sum = wave_sum_f64(sum);
     const float mean = (float)(sum / H);
     double sq = 0.0;
 #pragma unroll
@@ -43,8 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                   (double)(v[j].w * v[j].w);
         }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    sq = wave_sum_f64(sq);
     const float var = (float)(sq / H);
     const float scale = 1.0f / sqrtf(var + eps);
 #pragma unroll
