@@ -290,7 +290,34 @@ static bool use_big_tile(const GemmArgs& a) {
 
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (epi != EPI_PATCH && use_big_tile(a)) return launch_gemm2(dt, epi, a, st);
+    if (epi != EPI_PATCH && use_big_tile(a)) {
+        // A few tiles past a whole number of rounds cost the persistent kernel a full extra round (QKV at batch 32: 2 064
+        // tiles = 8 rounds + 16 tiles -> 9).  Then the last row panels go to the small-tile kernel instead: it fills the
+        // chip with them for a fraction of a tile time, and both kernels produce identical bits
+        // (test_gemm_small_and_large_m_agree_bit_for_bit).  DINOV2_HIP_GEMM_SPLIT=0 disables.
+        static const bool split_ok = [] {
+            const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
+            return !e || atoi(e) != 0;
+        }();
+        const int ntn = a.N / 256, ntm = (a.M + 255) / 256;
+        const long tiles = (long)ntn * ntm;
+        const long rounds = tiles / 256, rem = tiles % 256;
+        if (split_ok && rounds >= 2 && rem > 0 && rem <= 40 && epi != EPI_SWIGLU) {
+            const int panels1 = (int)(rounds * 256 / ntn);  // row panels the persistent kernel can take in `rounds` rounds
+            const int M1 = panels1 * 256;
+            if (M1 > 0 && M1 < a.M) {
+                GemmArgs a1 = a, a2 = a;
+                a1.M = M1;
+                a2.M = a.M - M1;
+                a2.A = (const char*)a.A + (size_t)M1 * a.K * 2;
+                const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
+                a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
+                const hipError_t e = launch_gemm2(dt, epi, a1, st);
+                return e != hipSuccess ? e : launch_gemm(dt, epi, a2, st);  // the tail is small: takes the path below
+            }
+        }
+        return launch_gemm2(dt, epi, a, st);
+    }
     // small problems (batch 1: M = 1374): 128x128 tiles leave most CUs idle and one workgroup per CU cannot hide the
     // global -> LDS latency of its K loop.  64x128 tiles with 2 LDS stages (48 KiB: three workgroups per CU hide each other's
     // latency) when there are enough tiles, with 3 stages (72 KiB) when there are not (N = 1024 at batch 1: 176 tiles; the
