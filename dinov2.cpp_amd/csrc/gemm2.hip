@@ -328,6 +328,29 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                         for (int ii = 0; ii < 2; ++ii) {
                             const int i = 2 * q + ii;
                             vec4 o;
+#ifndef DINO_GELU_SCALAR
+                            if constexpr (EPI == EPI_GELU) {
+                                // Two columns per instruction: the bias add, x^2, the cubic, 1 + 2^t and the final product
+                                // run as v_pk_*_f32 (IEEE results identical to the scalar ops of gemm.hip, so both kernels
+                                // still agree bit for bit); v_exp / v_rcp / the f16 conversions stay per element.  The GELU
+                                // epilogue was ~24 % of this kernel: 9.5 VALU + 2 transcendental instructions per element.
+                                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                                for (int e2 = 0; e2 < 2; ++e2) {
+                                    f32x2 v = {acc[j][i][4 * g + 2 * e2], acc[j][i][4 * g + 2 * e2 + 1]};
+                                    v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
+                                    asm volatile("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
+                                    const f32x2 xr = {(float)(_Float16)v[0], (float)(_Float16)v[1]};
+                                    const f32x2 c1 = {-0.1029432397f, -0.1029432397f}, c2 = {-2.302208199f, -2.302208199f};
+                                    const f32x2 t = xr * __builtin_elementwise_fma(xr * xr, c1, c2);  // -2 log2(e) u
+                                    const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                                    f32x2 gl = xr * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                                    asm volatile("" : "+v"(gl));
+                                    o[2 * e2] = E::from_f32((float)(_Float16)gl[0]);
+                                    o[2 * e2 + 1] = E::from_f32((float)(_Float16)gl[1]);
+                                }
+                            } else
+#endif
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 float v = acc[j][i][4 * g + e] + bb[e];
