@@ -239,3 +239,21 @@ def test_image_result_independent_of_batch_size(api, pkg, tmp_path):
         one = sess.predict(imgs[b:b + 1], classify=True)
         assert np.array_equal(one["logits"][0], full["logits"][b])
         assert np.array_equal(one["patch_tokens"][0], full["patch_tokens"][b])
+
+
+@pytest.mark.parametrize("dtype_name,scale", [("f16", 1.0), ("bf16", 8.0)])
+def test_full_size_giant_swiglu(api, pkg, tmp_path, dtype_name, scale):
+    """BASELINE config 4 shapes (ViT-g/14: H = 1536, 24 heads, SwiGLU 8192 -> 4096; 2 of its 40 layers to keep the oracle
+    in seconds) at 518x518, batch 6 so that the persistent 256x256 kernel and its SwiGLU epilogue are the ones running:
+    first and last image against the oracle, f16 and bf16 compute."""
+    path = str(tmp_path / "giant2.gguf")
+    pkg.synth.write_synthetic_gguf(path, "giant", registers=4, num_classes=1000, seed=13, layers=2)
+    imgs = pkg.synth.synthetic_images(6, 518, 518, seed=13)
+    dt = api.F16 if dtype_name == "f16" else api.BF16
+    got = api.Session(api.Model(path, dtype=dt, classify=True)).predict(imgs, classify=True)
+    ora = OracleModel(path)
+    for b in (0, 5):
+        exp = ora.forward(imgs[b], classify=True)
+        assert _rel(got["logits"][b], exp["logits"]) <= 1e-3 * scale
+        assert _rel(got["patch_tokens"][b], exp["patch_tokens"]) <= 5e-3 * scale
+    np.testing.assert_allclose(got["probs"].sum(-1), 1.0, atol=1e-5)
