@@ -180,7 +180,10 @@ def main():
                                 "algorithmic bytes/launch = %d" % int(2 * M * H + 2 * H * F + 2 * M * F),
                 "flops_per_launch": flops_launch[dom], "avg_launch_ms": kernels.get(dom, {}).get("avg_ms"),
                 "whole_forward_tflops": round(value / world * gflop_img / 1e3, 1),
-                "whole_forward_frac": round(value / world * gflop_img / 1e3 / MFMA_PEAK_TFLOPS, 4)}
+                "whole_forward_frac": round(value / world * gflop_img / 1e3 / MFMA_PEAK_TFLOPS, 4),
+                # context, not the contract's peak: what v_mfma_f32_32x32x16_f16 alone sustains on random f16 operands on
+                # this power-limited part (tools/probes/mfma_peak.hip; 2 480 TF on zeros)
+                "sustained_mfma_tflops_random_operands": 1750.0, "frac_of_sustained": round(ach / 1750.0, 4)}
 
     # ---- p50 latency at batch 1 (the other half of BASELINE.json's metric) ----
     p50 = p99 = None
