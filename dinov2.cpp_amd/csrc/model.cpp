@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <numeric>
@@ -462,6 +463,9 @@ int ensure_workspace(dinov2_hip_session* s, int B, int h, int w, char* err, size
     const Carve c = carve_of(s->model, B, h, w);
     if (c.total > s->ws_bytes) {
         HIP_TRY(hipStreamSynchronize(s->stream));
+        for (auto& g : s->graphs)  // captured graphs point into the old workspace
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        s->graphs.clear();
         if (s->ws) HIP_TRY(hipFree(s->ws));
         s->ws = nullptr;
         s->ws_bytes = 0;
@@ -533,6 +537,25 @@ void drain_profile(dinov2_hip_session* s) {
 }
 
 // The forward pass: forward_features (dinov2.cpp:616-790) [+ forward_head :792-821], `nlayers` <= L layers.
+// pos-embed for this grid, cached per (h0, w0): the reference recomputes it on every call (dinov2.cpp:937).  Host work +
+// synchronisation: must run BEFORE a stream capture, never inside one.
+int prepare_pos(dinov2_hip_session* s, int B, int h, int w, char* err, size_t errlen) {
+    const dinov2_hip_model* m = s->model;
+    const int H = (int)m->hp.hidden_size, ps = (int)m->hp.patch_size;
+    const int h0 = h / ps, w0 = w / ps;
+    if (s->pos_h == h0 && s->pos_w == w0) return DINOV2_HIP_OK;
+    const Dims d = dims_of(m, B, h, w);
+    hipStream_t st = s->stream;
+    HIP_TRY(hipStreamSynchronize(st));  // pos_stage may still be in flight from a previous shape
+    s->pos_stage.resize((size_t)(1 + d.P) * H);
+    interpolate_pos_embed(m->pos_host.data(), (int)(m->hp.img_size / m->hp.patch_size), H, h0, w0, s->pos_stage.data());
+    HIP_TRY(hipMemcpyAsync(s->pos, s->pos_stage.data(), sizeof(float) * s->pos_stage.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    s->pos_h = h0;
+    s->pos_w = w0;
+    return DINOV2_HIP_OK;
+}
+
 // `img` is a DEVICE pointer.  Leaves final-LN tokens in s->fin, logits/probs in s->logits/s->probs.
 int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int layout, bool classify, int nlayers,
             bool finalize, char* err, size_t errlen) {
@@ -544,16 +567,9 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
     hipStream_t st = s->stream;
     const DType dt = m->dt;
 
-    // pos-embed for this grid, cached per (h0, w0): the reference recomputes it on every call (dinov2.cpp:937)
-    if (s->pos_h != h0 || s->pos_w != w0) {
-        HIP_TRY(hipStreamSynchronize(st));  // pos_stage may still be in flight from a previous shape
-        s->pos_stage.resize((size_t)(1 + d.P) * H);
-        interpolate_pos_embed(m->pos_host.data(), (int)(m->hp.img_size / m->hp.patch_size), H, h0, w0,
-                              s->pos_stage.data());
-        HIP_TRY(hipMemcpyAsync(s->pos, s->pos_stage.data(), sizeof(float) * s->pos_stage.size(), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        s->pos_h = h0;
-        s->pos_w = w0;
+    {
+        const int rcp = prepare_pos(s, B, h, w, err, errlen);  // no-op when predict already did it (graph capture relies on that)
+        if (rcp != DINOV2_HIP_OK) return rcp;
     }
 
     {
@@ -657,6 +673,70 @@ int check_input(const dinov2_hip_session* s, const dinov2_hip_input* in, char* e
     return DINOV2_HIP_OK;
 }
 
+// Opt-in (DINOV2_HIP_GRAPHS=1): second and later forwards with the same (workspace, input pointer, shape, flags) replay a
+// captured hipGraph; the first occurrence runs eagerly (one-off shapes never pay for a capture), the second is captured.
+// Off by default because it buys nothing on an idle host: the forward is kernel-bound (178 launches, mean gap 1.0 us in the
+// rocprofv3 trace at batch 1), measured p50 3.07 ms with graphs vs 3.06 ms without.  It is there for hosts whose launch
+// thread is contended.
+int forward_maybe_graph(dinov2_hip_session* s, const float* img, int B, int h, int w, int layout, bool classify, char* err,
+                        size_t errlen) {
+    static const bool enabled = [] {
+        const char* e = getenv("DINOV2_HIP_GRAPHS");
+        return e && atoi(e) != 0;
+    }();
+    const int nl = (int)s->model->hp.num_hidden_layers;
+    if (!enabled || s->profiling) return forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);
+    hipStream_t st = s->stream;
+    dinov2_hip_session::GraphEntry* hit = nullptr;
+    for (auto& g : s->graphs)
+        if (g.ws == s->ws && g.img == img && g.b == B && g.h == h && g.w == w && g.layout == layout && g.classify == (int)classify)
+            hit = &g;
+    if (hit && hit->exec) {
+        ++hit->uses;
+        HIP_TRY(hipGraphLaunch(hit->exec, st));
+        return DINOV2_HIP_OK;
+    }
+    if (hit && hit->uses < 0) return forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);  // capture failed before
+    if (!hit) {  // first sighting: remember it, run eagerly
+        if (s->graphs.size() >= 8) {  // evict the least used entry
+            size_t v = 0;
+            for (size_t i = 1; i < s->graphs.size(); ++i)
+                if (s->graphs[i].uses < s->graphs[v].uses) v = i;
+            if (s->graphs[v].exec) (void)hipGraphExecDestroy(s->graphs[v].exec);
+            s->graphs.erase(s->graphs.begin() + (long)v);
+        }
+        s->graphs.push_back({s->ws, img, B, h, w, layout, (int)classify, 0, nullptr});
+        return forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);
+    }
+    // second sighting: capture.  Nothing in forward() synchronises or allocates once prepare_pos has run.
+    if (hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        return forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);
+    }
+    const int rc = forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(st, &graph);
+    if (rc != DINOV2_HIP_OK || ec != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        hit->uses = -1000000;  // do not try again for this key
+        if (rc != DINOV2_HIP_OK) return rc;
+        return forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        hit->uses = -1000000;
+        return forward(s, img, B, h, w, layout, classify, nl, true, err, errlen);
+    }
+    hit->exec = exec;
+    hit->uses = 1;
+    HIP_TRY(hipGraphLaunch(exec, st));
+    return DINOV2_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int dinov2_hip_session_create(dinov2_hip_model* m, void* stream, dinov2_hip_session** out, char* err,
@@ -685,6 +765,8 @@ extern "C" void dinov2_hip_session_free(dinov2_hip_session* s) {
     (void)hipStreamSynchronize(s->stream);
     drain_profile(s);
     for (auto e : s->free_events) (void)hipEventDestroy(e);
+    for (auto& g : s->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (s->ws) (void)hipFree(s->ws);
     if (s->raw) (void)hipFree(s->raw);
     if (s->own_stream) (void)hipStreamDestroy(s->stream);
@@ -784,7 +866,9 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
         HIP_TRY(hipMemcpyAsync(s->img, in->data, sizeof(float) * 3 * (size_t)B * h * w, hipMemcpyHostToDevice, st));
         img = s->img;
     }
-    rc = forward(s, img, B, h, w, layout, classify, (int)m->hp.num_hidden_layers, true, err, errlen);
+    rc = prepare_pos(s, B, h, w, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    rc = forward_maybe_graph(s, img, B, h, w, layout, classify, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;
     if (!out) return DINOV2_HIP_OK;
 

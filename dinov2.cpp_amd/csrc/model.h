@@ -57,6 +57,15 @@ struct dinov2_hip_session {
     void *col = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
     int pos_h = -1, pos_w = -1;  // grid the cached interpolated pos-embed in `pos` belongs to
     std::vector<float> pos_stage;
+    // hipGraph cache (the "allocr reuse" of the reference taken one step further): a forward that repeats with the same
+    // shape, input pointer and workspace is captured once and replayed; 178 launches become one graph launch
+    struct GraphEntry {
+        const void* ws;
+        const void* img;
+        int b, h, w, layout, classify, uses;
+        hipGraphExec_t exec;
+    };
+    std::vector<GraphEntry> graphs;
     // profiling
     bool profiling = false;
     std::vector<ProfRecord> records;
