@@ -257,3 +257,36 @@ def test_full_size_giant_swiglu(api, pkg, tmp_path, dtype_name, scale):
         assert _rel(got["logits"][b], exp["logits"]) <= 1e-3 * scale
         assert _rel(got["patch_tokens"][b], exp["patch_tokens"]) <= 5e-3 * scale
     np.testing.assert_allclose(got["probs"].sum(-1), 1.0, atol=1e-5)
+
+
+def test_graph_replay_matches_eager(golden_dir):
+    """DINOV2_HIP_GRAPHS=1 (read once per process, hence the subprocess): eager, capture, replay and replay of the same
+    device-resident forward give identical bits; a different shape in between re-uploads its pos-embed and the replayed
+    graph of the first shape still sees the right one."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+from importlib import import_module
+from __graft_entry__ import PKG_NAME, load_package
+load_package(); api = import_module(PKG_NAME + ".api")
+sess = api.Session(api.Model(sys.argv[1], classify=True))
+g = torch.Generator().manual_seed(1)
+a = torch.randn(3, 3, 70, 98, generator=g).cuda(); b = torch.randn(2, 3, 42, 56, generator=g).cuda()
+def run(x):
+    B = x.shape[0]
+    lo = torch.empty(B, 10, device="cuda"); pr = torch.empty_like(lo)
+    sess.predict_device(x.data_ptr(), B, x.shape[2], x.shape[3], classify=True, layout=api.RGB_CHW, logits_ptr=lo.data_ptr(), probs_ptr=pr.data_ptr())
+    sess.sync()
+    return lo.cpu().numpy()
+r = [run(a), run(a), run(a), run(b), run(a), run(b), run(b), run(a)]
+assert all(np.array_equal(r[0], r[i]) for i in (1, 2, 4, 7)), "graph replay differs from eager"
+assert np.array_equal(r[3], r[5]) and np.array_equal(r[3], r[6])
+print("GRAPH_OK")
+'''
+    env = dict(os.environ, DINOV2_HIP_GRAPHS="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(golden_dir, "tiny_gelu_reg4.gguf")], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert "GRAPH_OK" in out.stdout, out.stdout + out.stderr
