@@ -21,6 +21,12 @@
 //     O^T keeps q on the lane axis, so the online-softmax rescale and the final 1/l are lane-local too.
 //   * K and V tiles are staged HBM -> LDS by global_load_lds_dwordx4, double buffered, 128-byte rows with the same
 //     16-byte-chunk XOR swizzle as the GEMM.
+//   * 1-D grid, XCD-aware: all query blocks of an (image, head) run on one XCD, so its K/V is fetched from HBM once.
+//
+// Two kernels with this mapping and identical arithmetic (bit-for-bit equal outputs, tested): attention_kernel (121 VGPRs,
+// four workgroups per CU overlap each other -- the throughput kernel) and attention2_kernel (software-pipelined inside
+// the wave, 2 waves per SIMD -- wins when there are too few workgroups to overlap, i.e. small batches).  launch_attention
+// picks by workgroup count.
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
