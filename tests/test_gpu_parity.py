@@ -189,11 +189,12 @@ def test_full_size_large_properties(api, pkg, tmp_path):
 
 
 @pytest.mark.parametrize("name", ["tiny_gelu_reg4", "tiny_swiglu_reg4"])
-@pytest.mark.parametrize("h,w", [(14, 14), (14, 70), (154, 98), (406, 406)])
+@pytest.mark.parametrize("h,w", [(14, 14), (14, 70), (154, 98), (406, 406), (490, 854)])
 def test_shape_edge_cases(api, golden_dir, name, h, w):
     """Extremes of the token count: a single patch (T = 6: one partial key tile, one partial query block), a 1 x 5 strip,
     a non-square 11 x 7 grid, and 29 x 29 = 841 patches (T = 846: 14 key tiles, 7 query blocks, pos-embed upsampled from
-    5 x 5) -- classify and features against the oracle."""
+    5 x 5), and the realtime demo's 854 x 480 frame rounded to patches (35 x 61 = 2 135 patches) -- classify and features
+    against the oracle."""
     gguf = os.path.join(golden_dir, name + ".gguf")
     sess = api.Session(api.Model(gguf, classify=True))
     ora = OracleModel(gguf)
