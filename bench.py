@@ -200,6 +200,31 @@ def main():
         p50 = round(float(np.median(lat[20:])), 3)
         p99 = round(float(np.percentile(lat[20:], 99)), 3)
 
+    # ---- side measurement, NOT the headline: the same batch split over two sessions (two HIP streams) on this GPU.  The other
+    #      stream's kernels fill the idle CUs of a GEMM's last round; per-kernel durations of overlapped launches would mean
+    #      nothing against the roofline, so `value` and `roofline` above stay single-stream (profiles/r01_gemm_tuning.md 7).
+    two_stream = None
+    if world == 1 and B >= 2 and B % 2 == 0 and not args.no_latency:
+        pair = [api.Session(model), api.Session(model)]
+        hb = B // 2
+
+        def step2():
+            for i, sx in enumerate(pair):
+                sx.predict_device(imgs[i * hb:(i + 1) * hb].data_ptr(), hb, S, S, classify=True, layout=api.RGB_CHW,
+                                  logits_ptr=logits[i * hb:(i + 1) * hb].data_ptr(), probs_ptr=probs[i * hb:(i + 1) * hb].data_ptr())
+            for sx in pair:
+                sx.sync()
+
+        for _ in range(2):
+            step2()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            step2()
+        torch.cuda.synchronize()
+        two_stream = round(B * 5 / (time.perf_counter() - t0), 2)
+        del pair
+
     # ---- CPU baseline: the oracle (restatement of the reference graph) on the host cores, bounded sample ----
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
@@ -229,6 +254,7 @@ def main():
                    "global_batch": world * B, "tokens_per_image": T, "parallelism": f"dp{world}",
                    "gflop_per_image": round(gflop_img, 1)},
         "p50_latency_ms_batch1": p50, "p99_latency_ms_batch1": p99,
+        "two_sessions_images_per_sec": two_stream,
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }
