@@ -260,7 +260,9 @@ static hipError_t set_attr_cfg() {
     return e;
 }
 
-hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);  // gemm2.hip
+hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);      // gemm2.hip, 256-row tiles
+hipError_t launch_gemm2_192(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);  // gemm2.hip, 192-row tiles
+hipError_t launch_gemm2_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 hipError_t gemm2_init();
 
 hipError_t gemm_init() {
@@ -291,10 +293,13 @@ static bool use_big_tile(const GemmArgs& a) {
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (epi != EPI_PATCH && use_big_tile(a)) {
-        // A few tiles past a whole number of rounds cost the persistent kernel a full extra round (QKV at batch 32: 2 064
-        // tiles = 8 rounds + 16 tiles -> 9).  Then the last row panels go to the small-tile kernel instead: it fills the
-        // chip with them for a fraction of a tile time, and both kernels produce identical bits
-        // (test_gemm_small_and_large_m_agree_bit_for_bit).  DINOV2_HIP_GEMM_SPLIT=0 disables.
+        // Tile-count quantisation.  The persistent kernel works in rounds of 256 tiles; a partial last round costs a whole one
+        // (QKV at batch 32: 2 064 tiles = 8 rounds + 16 -> 9; out-proj / FFN-out: 688 = 2.69 -> 3).  Two remedies, both
+        // bit-neutral (every kernel here produces the same bits for a row: test_gemm_small_and_large_m_agree_bit_for_bit):
+        //   * a handful of left-over tiles: those row panels go to the small-tile kernel, which spreads them over the chip;
+        //   * a sizeable partial round: the whole rounds run 256-row tiles, the remaining rows 192-row tiles, in ONE launch
+        //     (gemm2_mixed_kernel): 2 + 0.79 instead of 3 tile times.  Measured: QKV 0.292 -> 0.285 ms, out-proj 0.129 ->
+        //     0.125, FFN-in 0.402 -> 0.401, FFN-out 0.393 -> 0.374.  DINOV2_HIP_GEMM_SPLIT=0 disables both.
         static const bool split_ok = [] {
             const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
             return !e || atoi(e) != 0;
@@ -302,7 +307,8 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const int ntn = a.N / 256, ntm = (a.M + 255) / 256;
         const long tiles = (long)ntn * ntm;
         const long rounds = tiles / 256, rem = tiles % 256;
-        if (split_ok && rounds >= 2 && rem > 0 && rem <= 40 && epi != EPI_SWIGLU) {
+        const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
+        if (split_ok && rounds >= 1 && rem > 0 && epi != EPI_SWIGLU) {
             const int panels1 = (int)(rounds * 256 / ntn);  // row panels the persistent kernel can take in `rounds` rounds
             const int M1 = panels1 * 256;
             if (M1 > 0 && M1 < a.M) {
@@ -310,10 +316,14 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
                 a1.M = M1;
                 a2.M = a.M - M1;
                 a2.A = (const char*)a.A + (size_t)M1 * a.K * 2;
-                const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
                 a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
-                const hipError_t e = launch_gemm2(dt, epi, a1, st);
-                return e != hipSuccess ? e : launch_gemm(dt, epi, a2, st);  // the tail is small: takes the path below
+                const long tiles192 = (long)ntn * ((a2.M + 191) / 192);
+                if (rem <= 40 && rounds >= 2) {  // a handful of tiles: the small-tile kernel fills the chip with them
+                    const hipError_t e = launch_gemm2(dt, epi, a1, st);
+                    return e != hipSuccess ? e : launch_gemm(dt, epi, a2, st);  // the tail is small: takes the path below
+                }
+                if (tiles192 <= 256 && tiles192 >= 128 && (long)panels1 * ntn >= 256)
+                    return launch_gemm2_mixed(dt, epi, a1, a2, st);
             }
         }
         return launch_gemm2(dt, epi, a, st);

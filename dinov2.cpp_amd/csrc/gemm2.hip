@@ -27,8 +27,12 @@
 
 namespace dinov2 {
 
-template <typename T, int EPI>
-__global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
+// XREP = 32-row MFMA blocks per wave along M: 4 -> 256-row tiles (the main configuration), 3 -> 192-row tiles, used by the
+// dispatcher for the LAST partial round of a launch (688 tiles of 256 rows on 256 CUs are 2.69 rounds -> 3; two rounds of
+// 256-row tiles plus one round of 192-row tiles cover the same rows in 2.79).  Same instruction schedule minus the fourth
+// activation fragment; same K order, so a row's bits do not depend on the tile height.
+template <typename T, int EPI, int XREP>
+static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem) {
     // No implicit mul+add -> fma contraction anywhere in this kernel: the unrolled epilogue instances would otherwise be
     // contracted differently, making an output element's last f32 bit (and, after the f16 rounding, occasionally its
     // value) depend on WHERE its row sits in the tile.  B images must equal B independent forwards bit for bit.
@@ -36,14 +40,16 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
-    constexpr int BM = 256, BN = 256, BK = 64, NW = 8;
+    constexpr int BM = 64 * XREP, BN = 256, BK = 64, NW = 8;
     constexpr int ROWB = BK * 2;
-    constexpr int STAGE = (BM + BN) * ROWB;  // 64 KiB per K-tile, two stages
-    constexpr int XREP = 4, WREP = 2;        // wave tile: 128 tokens x 64 output columns
+    constexpr int STAGE = 512 * ROWB;  // 64 KiB per K-tile (X rows at 0, W rows at BM * ROWB), two stages
+    constexpr int WREP = 2;                  // wave tile: 32 * XREP tokens x 64 output columns
+    constexpr int WOFF = BM * ROWB;          // LDS offset of the weight rows inside a stage
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // opaque: when two bodies run back to back (gemm2_mixed_kernel) nothing lane-derived is
+                                     // shared between them and kept live across the first one's loops
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, N = p.N, K = p.K;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
             const int lc = (lane & 7) ^ ((row >> 1) & 7);
             int gm = m0 + row;
             gm = gm < M ? gm : M - 1;
-            xsrc[j] = (unsigned)gm * (unsigned)(K * 2) + lc * 16;
+            if (j < XREP) xsrc[j] = (unsigned)gm * (unsigned)(K * 2) + lc * 16;
             wsrc[j] = (unsigned)(n0 + row) * (unsigned)(K * 2) + lc * 16;
         }
     };
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         const char* ga = (const char*)p.A + (size_t)kt * (BK * 2);
         const char* gw = (const char*)p.W + (size_t)kt * (BK * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(ga + xsrc[j], sX + (j * NW + wid) * 8 * ROWB);
+        for (int j = 0; j < XREP; ++j) glds16(ga + xsrc[j], sX + (j * NW + wid) * 8 * ROWB);
 #pragma unroll
         for (int j = 0; j < 4; ++j) glds16(gw + wsrc[j], sW + (j * NW + wid) * 8 * ROWB);
     };
@@ -101,6 +107,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     // one of the 8 wave-instructions of a K-tile (0-3: activation rows, 4-7: weight rows); j is a literal at every call
     auto piece = [&](int buf, int kt, int j) {
         if (DINO_GEMM_DBG & 2) return;
+        if (j < 4 && j >= XREP) return;  // 192-row tiles have three activation pieces
         char* dst = smem + buf * STAGE + (j < 4 ? 0 : BM * ROWB) + ((j & 3) * NW + wid) * 8 * ROWB;
         const char* src = (j < 4 ? (const char*)p.A + xsrc[j & 3] : (const char*)p.W + wsrc[j & 3]) + (size_t)kt * (BK * 2);
         glds16(src, dst);
@@ -110,8 +117,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     const int grp = wid >> 2;  // waves 0-3 / 4-7: the two waves that share each SIMD
     const int fr = lane & 31, fh = lane >> 5;
     const int sw = (fr >> 1) & 7;
-    const int xoff = (wx * 128 + fr) * ROWB;
-    const int woff = (ww * 64 + fr) * ROWB;  // + BM*ROWB = 32768 goes into the instruction offset
+    const int xoff = (wx * (32 * XREP) + fr) * ROWB;
+    const int woff = (ww * 64 + fr) * ROWB;  // + WOFF goes into the instruction offset
 
     const unsigned lds0 = (unsigned)(uintptr_t)(DINO_LDS_AS char*)smem;
     unsigned xaddr[4], waddr[4];  // per k-step LDS byte address of this lane's first X / W fragment row (stage 0)
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         int m0, n0;
         tile_mn(chunk0 + tix, m0, n0);
 
-        f32x16 acc[WREP][XREP];
+        f32x16 acc[WREP][4];  // [.][3] untouched (and eliminated) when XREP == 3
 #pragma unroll
         for (int j = 0; j < WREP; ++j)
 #pragma unroll
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
-        u32x4 xf0[XREP], wf0[WREP], xf1[XREP], wf1[WREP];
+        u32x4 xf0[4], wf0[WREP], xf1[4], wf1[WREP];
 
         // ---- main loop ---------------------------------------------------------------------------------------------
         // Rules followed for the inline-asm reads (cdna_hip_programming.md 5.7): every asm read is waited for by an asm
@@ -163,13 +170,14 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         DINO_DSR(XF[0], xa__, 0);                                                \
         DINO_DSR(XF[1], xa__, 4096);                                             \
         DINO_DSR(XF[2], xa__, 8192);                                             \
-        DINO_DSR(XF[3], xa__, 12288);                                            \
-        DINO_DSR(WF[0], wa__, 32768);                                            \
-        DINO_DSR(WF[1], wa__, 36864);                                            \
+        if (XREP == 4) DINO_DSR(XF[3], xa__, 12288);                             \
+        DINO_DSR(WF[0], wa__, WOFF);                                             \
+        DINO_DSR(WF[1], wa__, WOFF + 4096);                                      \
     }
-#define DINO_WAIT_LGKM(N)                                   \
-    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory"); \
+#define DINO_WAIT_LGKM(N)                                         \
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");    \
     __builtin_amdgcn_sched_barrier(0);
+    constexpr int NRD = XREP + WREP;  // fragment reads per k-step
 #if DINO_GEMM_DBG & 512  // experiment: raise the wave's priority around its MFMA runs
 #define DINO_PRIO(P) __builtin_amdgcn_s_setprio(P)
 #else
@@ -205,8 +213,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         S2;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
         DINO_PRIO(1);                              \
-        DINO_MFMA1(XF, WF, 3, 0)                   \
-        DINO_MFMA1(XF, WF, 3, 1)                   \
+        if (XREP == 4) {                           \
+            DINO_MFMA1(XF, WF, 3, 0)               \
+            DINO_MFMA1(XF, WF, 3, 1)               \
+        }                                          \
         DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S3;                                        \
@@ -235,15 +245,15 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
             const bool more = kt + 1 < nk;      // K-tile kt+1 exists: its pieces 0-2 were issued behind the last barrier,
                                                 // pieces 3-7 go out with the first two MFMA groups of this iteration
             DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
-            DINO_WAIT_LGKM(6);                  // the older six (k-step 0) have returned
+            DINO_WAIT_LGKM(NRD);                  // the older six (k-step 0) have returned
             DINO_MFMAS_P(xf0, wf0, DINO_SLOT_A(more, nb, kt + 1, 3), DINO_SLOT_AB(more, nb, kt + 1, 4, 3),
                          DINO_SLOT_AB(more, nb, kt + 1, 5, 4), DINO_SLOT_B(more, nb, kt + 1, 5));
             DINO_LOAD_FRAGS(xf0, wf0, cur, 2);
-            DINO_WAIT_LGKM(6);
+            DINO_WAIT_LGKM(NRD);
             DINO_MFMAS_P(xf1, wf1, DINO_SLOT_A(more, nb, kt + 1, 6), DINO_SLOT_AB(more, nb, kt + 1, 7, 6),
                          DINO_SLOT_B(more, nb, kt + 1, 7), );
             DINO_LOAD_FRAGS(xf1, wf1, cur, 3);
-            DINO_WAIT_LGKM(6);
+            DINO_WAIT_LGKM(NRD);
             DINO_MFMAS(xf0, wf0);               // no staging here: slack for K-tile kt+1 to land before the barrier
             // k-step-3 fragments (issued one MFMA group ago) must be in registers before the barrier: after it nobody
             // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
         asm volatile("" : "+v"(el));
         const int er = el & 31, eh = el >> 5;
         char* const ep = smem + STAGE + wid * 8192;
-        const int mbase = m0 + wx * 128;
+        const int mbase = m0 + wx * (32 * XREP);
         const int ncol = n0 + ww * 64 + 4 * eh;
 
         float4 bs[WREP][4];
@@ -327,6 +337,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #pragma unroll
                         for (int ii = 0; ii < 2; ++ii) {
                             const int i = 2 * q + ii;
+                            if (i >= XREP) continue;  // 192-row tiles: the second pass has one 32-row block
                             vec4 o;
 #ifndef DINO_GELU_SCALAR
                             if constexpr (EPI == EPI_GELU) {
@@ -394,7 +405,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                         const int row = it * 16 + (el >> 2), slot = el & 3;
                         const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
                         const int m = mbase + q * 64 + row;
-                        if (m < M) *(u32x4*)((T*)p.out + (size_t)m * p.ldo + hid0 + slot * 8) = v;
+                        if (m < M && (XREP == 4 || q * 64 + row < 32 * XREP))
+                            *(u32x4*)((T*)p.out + (size_t)m * p.ldo + hid0 + slot * 8) = v;
                     }
                 } else {
 #pragma unroll
@@ -402,7 +414,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                         const int row = it * 8 + (el >> 3), slot = el & 7;
                         const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
                         const int m = mbase + q * 64 + row;
-                        if (m < M) *(u32x4*)((T*)p.out + (size_t)m * p.ldo + n0 + ww * 64 + slot * 8) = v;
+                        if (m < M && (XREP == 4 || q * 64 + row < 32 * XREP))
+                            *(u32x4*)((T*)p.out + (size_t)m * p.ldo + n0 + ww * 64 + slot * 8) = v;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -436,6 +449,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #pragma unroll
                     for (int ii = 0; ii < 2; ++ii) {
                         const int i = 2 * q + ii;
+                        if (i >= XREP) continue;
                         const int row = ii * 32 + er;
                         const int slot = (2 * g + eh) ^ (row & 7);
                         *(float4*)(ep + row * 128 + slot * 16) =
@@ -451,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
                     if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH)
                         v = make_float4(v.x + add[it].x, v.y + add[it].y, v.z + add[it].z, v.w + add[it].w);
                     const int m = mbase + q * 64 + row;
-                    if (m < M) {
+                    if (m < M && (XREP == 4 || q * 64 + row < 32 * XREP)) {
                         size_t o;
                         if constexpr (EPI == EPI_PATCH) {
                             const int b = m / p.P, pp = m - b * p.P;
@@ -470,14 +484,31 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 #undef DINO_TS
 }
 
-template <typename T>
+template <typename T, int EPI, int XREP>
+__global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm2_body<T, EPI, XREP>(p, smem);
+}
+
+// One launch, two tile heights: every block first walks its share of the 256-row tiles of `p` (whole rounds), then its share
+// of the 192-row tiles of `q` (the remaining rows).  No grid-wide barrier in between -- a block that is done with its
+// 256-row tiles starts on the 192-row ones at once -- which is what two back-to-back launches lacked (they were slower
+// than the plain kernel for K = 1024).
+template <typename T, int EPI>
+__global__ __launch_bounds__(512) void gemm2_mixed_kernel(GemmArgs p, GemmArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    gemm2_body<T, EPI, 4>(p, smem);
+    gemm2_body<T, EPI, 3>(q, smem);
+}
+
+template <typename T, int XREP>
 static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
-    const int tiles = (a.N / 256) * ((a.M + 255) / 256);
+    const int tiles = (a.N / 256) * ((a.M + 64 * XREP - 1) / (64 * XREP));
     const dim3 grid(tiles < 256 ? tiles : 256), block(512);
     const size_t lds = 2 * 512 * 128;
 #define DINO_L2(E)                                                         \
     case E:                                                                \
-        hipLaunchKernelGGL((gemm2_kernel<T, E>), grid, block, lds, st, a); \
+        hipLaunchKernelGGL((gemm2_kernel<T, E, XREP>), grid, block, lds, st, a); \
         break;
     switch (epi) {
         case EPI_PATCH: return hipErrorInvalidValue;  // patch-embed (0.16 % of FLOPs) stays on the 128x128 kernel
@@ -493,16 +524,45 @@ static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
 
 // requires N % 256 == 0 and (K / 64) even
 hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
-    return dt == DT_F16 ? launch2_t<_Float16>(epi, a, st) : launch2_t<__bf16>(epi, a, st);
+    return dt == DT_F16 ? launch2_t<_Float16, 4>(epi, a, st) : launch2_t<__bf16, 4>(epi, a, st);
 }
 
 template <typename T>
+static hipError_t launch2_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    const dim3 grid(256), block(512);
+    const size_t lds = 2 * 512 * 128;
+#define DINO_LM(E)                                                                  \
+    case E:                                                                         \
+        hipLaunchKernelGGL((gemm2_mixed_kernel<T, E>), grid, block, lds, st, a, b); \
+        break;
+    switch (epi) {
+        DINO_LM(EPI_QKV)
+        DINO_LM(EPI_RESID)
+        DINO_LM(EPI_GELU)
+        DINO_LM(EPI_PLAIN_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef DINO_LM
+    return hipGetLastError();
+}
+
+// 256-row tiles for `a` (must be >= 256 tiles), then 192-row tiles for `b`, in one launch (see gemm2_mixed_kernel)
+hipError_t launch_gemm2_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    return dt == DT_F16 ? launch2_mixed_t<_Float16>(epi, a, b, st) : launch2_mixed_t<__bf16>(epi, a, b, st);
+}
+
+// same kernel with 192-row tiles (see gemm2_kernel)
+hipError_t launch_gemm2_192(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    return dt == DT_F16 ? launch2_t<_Float16, 3>(epi, a, st) : launch2_t<__bf16, 3>(epi, a, st);
+}
+
+template <typename T, int XREP>
 static hipError_t attr2_t() {
     hipError_t e = hipSuccess;
     const int lds = 2 * 512 * 128;
 #define DINO_A2(E)                                                                  \
     if (e == hipSuccess)                                                            \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<T, E>), \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<T, E, XREP>), \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DINO_A2(EPI_QKV)
     DINO_A2(EPI_RESID)
@@ -510,12 +570,23 @@ static hipError_t attr2_t() {
     DINO_A2(EPI_SWIGLU)
     DINO_A2(EPI_PLAIN_F32)
 #undef DINO_A2
+#define DINO_A3(E)                                                                        \
+    if (e == hipSuccess && XREP == 4)                                                     \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_mixed_kernel<T, E>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    DINO_A3(EPI_QKV)
+    DINO_A3(EPI_RESID)
+    DINO_A3(EPI_GELU)
+    DINO_A3(EPI_PLAIN_F32)
+#undef DINO_A3
     return e;
 }
 
 hipError_t gemm2_init() {
-    hipError_t e = attr2_t<_Float16>();
-    if (e == hipSuccess) e = attr2_t<__bf16>();
+    hipError_t e = attr2_t<_Float16, 4>();
+    if (e == hipSuccess) e = attr2_t<__bf16, 4>();
+    if (e == hipSuccess) e = attr2_t<_Float16, 3>();
+    if (e == hipSuccess) e = attr2_t<__bf16, 3>();
     return e;
 }
 
