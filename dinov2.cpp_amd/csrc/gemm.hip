@@ -308,7 +308,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const long tiles = (long)ntn * ntm;
         const long rounds = tiles / 256, rem = tiles % 256;
         const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
-        if (split_ok && rounds >= 1 && rem > 0 && epi != EPI_SWIGLU) {
+        if (split_ok && rounds >= 1 && rem > 0) {
             const int panels1 = (int)(rounds * 256 / ntn);  // row panels the persistent kernel can take in `rounds` rounds
             const int M1 = panels1 * 256;
             if (M1 > 0 && M1 < a.M) {
@@ -318,7 +318,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
                 a2.A = (const char*)a.A + (size_t)M1 * a.K * 2;
                 a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
                 const long tiles192 = (long)ntn * ((a2.M + 191) / 192);
-                if (rem <= 40 && rounds >= 2) {  // a handful of tiles: the small-tile kernel fills the chip with them
+                if (rem <= 40) {  // a handful of tiles: the small-tile kernel fills the chip with them
                     const hipError_t e = launch_gemm2(dt, epi, a1, st);
                     return e != hipSuccess ? e : launch_gemm(dt, epi, a2, st);  // the tail is small: takes the path below
                 }

@@ -539,6 +539,7 @@ static hipError_t launch2_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArg
         DINO_LM(EPI_QKV)
         DINO_LM(EPI_RESID)
         DINO_LM(EPI_GELU)
+        DINO_LM(EPI_SWIGLU)
         DINO_LM(EPI_PLAIN_F32)
         default: return hipErrorInvalidValue;
     }
@@ -577,6 +578,7 @@ static hipError_t attr2_t() {
     DINO_A3(EPI_QKV)
     DINO_A3(EPI_RESID)
     DINO_A3(EPI_GELU)
+    DINO_A3(EPI_SWIGLU)
     DINO_A3(EPI_PLAIN_F32)
 #undef DINO_A3
     return e;

@@ -332,3 +332,19 @@ def test_gemm_small_and_large_m_agree_bit_for_bit(api, name, epi, N, K):
     big = np.ascontiguousarray(np.tile(x0, (32, 1)))
     _gemm(api, F16, epi, np.ascontiguousarray(np.tile(X, (32, 1))), W, bias, aux, big, 32 * T, N, K, N, qcols=N // 3, qscale=0.125)
     assert np.array_equal(big[:T], small) and np.array_equal(big[-T:], small)
+
+
+def test_gemm_swiglu_small_and_large_m_agree_bit_for_bit(api):
+    """SwiGLU epilogue: one image on the small-tile kernel vs the same rows inside 32 images on the persistent kernel with
+    its mixed 256/192-row schedule (5.4 rounds of tiles): identical bits."""
+    rng = np.random.default_rng(12)
+    T, K, F = 1374, 1024, 1024
+    X = _round(rng.standard_normal((T, K)), F16)
+    W = _round(rng.standard_normal((2 * F, K)) * 0.05, F16)
+    bias = rng.standard_normal(2 * F).astype(np.float32)
+    small = np.zeros((T, F), np.float32)
+    _gemm(api, F16, EPI_SWIGLU, X, W, bias, None, small, T, 2 * F, K, F)
+    big = np.zeros((32 * T, F), np.float32)
+    _gemm(api, F16, EPI_SWIGLU, np.ascontiguousarray(np.tile(X, (32, 1))), W, bias, None, big, 32 * T, 2 * F, K, F)
+    assert np.isfinite(small).all()
+    assert np.array_equal(big[:T], small) and np.array_equal(big[-T:], small)
