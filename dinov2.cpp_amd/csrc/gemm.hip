@@ -278,55 +278,75 @@ hipError_t gemm_init() {
 
 // Kernel choice: the 256x256 kernel (gemm2.hip) needs N % 256 == 0 (tiles must not straddle q|k|v or a SwiGLU pair,
 // and it has no N edge guards) and enough tiles to fill the 256 CUs; everything else takes the 128x128 kernel here.
-static bool use_big_tile(const GemmArgs& a) {
-    static const int forced = [] {  // tuning aid: DINOV2_HIP_GEMM_TILE=128|256
+// ---- which kernel(s) for a shape --------------------------------------------------------------------------------------
+// The persistent kernel (gemm2.hip; needs N % 256 == 0 and an even K / 64) works in rounds of 256 tiles, and a partial last
+// round costs a whole one (QKV at batch 32: 2 064 tiles of 256 rows = 8 rounds + 16 tiles -> 9; out-proj / FFN-out: 688 =
+// 2.69 -> 3; ViT-g at batch 8: 258 -> 2).  Every kernel here produces the same bits for a row
+// (test_gemm_small_and_large_m_agree_bit_for_bit), so the plan is chosen purely by estimated time, in units of one round of
+// 256-row tiles; a round of 192-row tiles is 0.79 (0.75 of the MFMA work, the same weight panel staged), the small-tile
+// kernel runs at about half the persistent kernel's rate:
+//   A  256-row tiles only                                   ceil(t256 / 256)
+//   B  192-row tiles only                                   ceil(t192 / 256) * 0.79
+//   C  whole rounds of 256-row tiles, rest 192-row tiles,   R + ceil(tail192 / 256) * 0.79      (gemm2_mixed_kernel)
+//      one launch
+//   D  whole rounds of 256-row tiles, rest small-tile       R + tail share of a round / 0.5 + 0.1 launch
+//      kernel (two launches; pays for a few left-over tiles)
+//   E  small-tile kernel only                               outputs / (256 tiles) / 0.5
+// Measured (M = 43 968): QKV 0.292 -> 0.285 ms (D), out-proj 0.129 -> 0.125 (C), FFN-out 0.393 -> 0.374 (C); ViT-g bf16 batch 8
+// 221 -> 244 images/s.  DINOV2_HIP_GEMM_SPLIT=0 restricts the choice to A / E, DINOV2_HIP_GEMM_TILE=128|256 forces E / A.
+hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    static const int forced = [] {
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
-    if (forced == 128) return false;
-    if (a.N % 256 != 0 || (a.K / 64) % 2 != 0) return false;  // gemm2 preconditions
-    if (forced == 256) return true;
-    const long tiles = (long)((a.M + 255) / 256) * (a.N / 256);
-    return tiles >= 192;
-}
-
-hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
-    if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (epi != EPI_PATCH && use_big_tile(a)) {
-        // Tile-count quantisation.  The persistent kernel works in rounds of 256 tiles; a partial last round costs a whole one
-        // (QKV at batch 32: 2 064 tiles = 8 rounds + 16 -> 9; out-proj / FFN-out: 688 = 2.69 -> 3).  Two remedies, both
-        // bit-neutral (every kernel here produces the same bits for a row: test_gemm_small_and_large_m_agree_bit_for_bit):
-        //   * a handful of left-over tiles: those row panels go to the small-tile kernel, which spreads them over the chip;
-        //   * a sizeable partial round: the whole rounds run 256-row tiles, the remaining rows 192-row tiles, in ONE launch
-        //     (gemm2_mixed_kernel): 2 + 0.79 instead of 3 tile times.  Measured: QKV 0.292 -> 0.285 ms, out-proj 0.129 ->
-        //     0.125, FFN-in 0.402 -> 0.401, FFN-out 0.393 -> 0.374.  DINOV2_HIP_GEMM_SPLIT=0 disables both.
-        static const bool split_ok = [] {
-            const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
-            return !e || atoi(e) != 0;
-        }();
-        const int ntn = a.N / 256, ntm = (a.M + 255) / 256;
-        const long tiles = (long)ntn * ntm;
-        const long rounds = tiles / 256, rem = tiles % 256;
-        const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
-        if (split_ok && rounds >= 1 && rem > 0) {
-            const int panels1 = (int)(rounds * 256 / ntn);  // row panels the persistent kernel can take in `rounds` rounds
-            const int M1 = panels1 * 256;
-            if (M1 > 0 && M1 < a.M) {
-                GemmArgs a1 = a, a2 = a;
-                a1.M = M1;
-                a2.M = a.M - M1;
-                a2.A = (const char*)a.A + (size_t)M1 * a.K * 2;
-                a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
-                const long tiles192 = (long)ntn * ((a2.M + 191) / 192);
-                if (rem <= 40) {  // a handful of tiles: the small-tile kernel fills the chip with them
-                    const hipError_t e = launch_gemm2(dt, epi, a1, st);
-                    return e != hipSuccess ? e : launch_gemm(dt, epi, a2, st);  // the tail is small: takes the path below
-                }
-                if (tiles192 <= 256 && tiles192 >= 128 && (long)panels1 * ntn >= 256)
-                    return launch_gemm2_mixed(dt, epi, a1, a2, st);
-            }
+    static const bool split_ok = [] {
+        const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
+        return !e || atoi(e) != 0;
+    }();
+    const bool big_ok = epi != EPI_PATCH && a.P != -1 && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
+    if (big_ok) {
+        const int ntn = a.N / 256;
+        const long t256 = (long)ntn * ((a.M + 255) / 256), t192 = (long)ntn * ((a.M + 191) / 192);
+        auto rnd = [](long t) { return (double)((t + 255) / 256); };
+        const double unit = 256.0 * 65536.0;  // outputs of one round of 256-row tiles
+        const double costE = (double)a.M * a.N / unit / 0.5;
+        char plan = 'A';
+        double best = rnd(t256);
+        if (forced == 256) {
+            best = -1.0;
+        } else {
+            if (t256 < 192 && costE < best) { plan = 'E'; best = costE; }  // far from filling the chip with big tiles
+            if (split_ok && t192 >= 192 && rnd(t192) * 0.79 < best - 0.02) { plan = 'B'; best = rnd(t192) * 0.79; }
         }
-        return launch_gemm2(dt, epi, a, st);
+        const long R = t256 / 256;
+        const int panels1 = (int)(R * 256 / ntn);
+        const int M1 = panels1 * 256;
+        GemmArgs a1 = a, a2 = a;
+        if (split_ok && forced != 256 && R >= 1 && M1 > 0 && M1 < a.M) {
+            const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
+            a1.M = M1;
+            a2.M = a.M - M1;
+            a2.A = (const char*)a.A + (size_t)M1 * a.K * 2;
+            a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
+            const long tail192 = (long)ntn * ((a2.M + 191) / 192);
+            const double costC = (double)R + rnd(tail192) * 0.79;
+            const double costD = (double)R + (double)a2.M * a.N / unit / 0.5 + 0.1;
+            if (costC < best - 0.02) { plan = 'C'; best = costC; }
+            if (costD < best - 0.02) { plan = 'D'; best = costD; }
+        }
+        switch (plan) {
+            case 'A': return launch_gemm2(dt, epi, a, st);
+            case 'B': return launch_gemm2_192(dt, epi, a, st);
+            case 'C': return launch_gemm2_mixed(dt, epi, a1, a2, st);
+            case 'D': {
+                const hipError_t e = launch_gemm2(dt, epi, a1, st);
+                if (e != hipSuccess) return e;
+                a2.P = -1;  // marks "tail of a split": go straight to the small-tile kernel below
+                return launch_gemm(dt, epi, a2, st);
+            }
+            default: break;  // 'E'
+        }
     }
     // small problems (batch 1: M = 1374): 128x128 tiles leave most CUs idle and one workgroup per CU cannot hide the
     // global -> LDS latency of its K loop.  64x128 tiles with 2 LDS stages (48 KiB: three workgroups per CU hide each other's
