@@ -168,8 +168,10 @@ def main():
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-        sym = {"f16": "gemm2_kernelIDF16_Li3E", "bf16": "gemm2_kernelIDF16bLi3E"}[args.dtype]
-        hit = [v for k, v in tj.items() if sym in k]
+        # FFN-in at this shape runs the mixed 256/192-row launch (gemm.hip plan C): one kernel per GEMM
+        syms = {"f16": ("gemm2_mixed_kernelIDF16_Li3E", "gemm2_kernelIDF16_Li3E"),
+                "bf16": ("gemm2_mixed_kernelIDF16bLi3E", "gemm2_kernelIDF16bLi3E")}[args.dtype]
+        hit = [v for sym in syms for k, v in tj.items() if sym in k][:1]
         if hit and args.model == "large" and B == 32 and not cfg["swiglu"]:
             traffic = round(hit[0]["hbm_bytes_per_launch_corrected"])
     except Exception:
