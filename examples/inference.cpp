@@ -1,0 +1,208 @@
+// inference.cpp -- the reference's `inference` program (/root/reference/inference.cpp:24-104) written against the C++ shim
+// (include/dinov2_compat.hpp) and the C-ABI, without OpenCV: same flags (dino_params_parse, dinov2.cpp:865-898), same stderr /
+// stdout lines ("main: graph computation took N ms" is what scripts/benchmark.sh:73-77 scrapes), same flow: read the image ->
+// dino_model_load -> preprocess -> timed dino_predict -> top-k lines, or a 3-component PCA of the patch tokens -> min-max to
+// 0..255 -> patch grid -> nearest-neighbour resize to the preprocessed size -> image file.
+// Images are binary PPM (P6): the reference's decoders live in OpenCV, which this build does not link.
+//
+//   g++ -O2 -std=c++17 -I include examples/inference.cpp -o inference dinov2.cpp_amd/libdinov2_hip.so -Wl,-rpath,$PWD/dinov2.cpp_amd
+//   ./inference -m model.gguf -i image.ppm [-c] [-k 5] [-o pca_visual.ppm]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "dinov2_compat.hpp"
+
+namespace {
+
+void print_usage(const char* prog, const dino_params& p) {  // dinov2.cpp:840-863
+    fprintf(stderr, "usage: %s [options]\n\noptions:\n", prog);
+    fprintf(stderr, "  -h, --help              show this help message and exit\n");
+    fprintf(stderr, "  -m FNAME, --model       model path (default: %s)\n", p.model.c_str());
+    fprintf(stderr, "  -i FNAME, --inp         input file, binary PPM (default: %s)\n", p.fname_inp.c_str());
+    fprintf(stderr, "  -o FNAME, --out         output file for backbone PCA features (default: %s)\n", p.image_out.c_str());
+    fprintf(stderr, "  -k N, --topk            top k classes to print (default: %u)\n", p.topk);
+    fprintf(stderr, "  -t N, --threads         number of threads to use during computation (default: %u)\n", p.n_threads);
+    fprintf(stderr, "  -c, --classify          whether to classify the image or get backbone PCA features (default: %d)\n", (int)p.classify);
+    fprintf(stderr, "  -fa, --flash_attn          whether to enable flash_attn, less accurate (default: %d)\n\n", (int)p.enable_flash_attn);
+}
+
+bool params_parse(int argc, char** argv, dino_params& p) {  // dinov2.cpp:865-898; -o sets the OUTPUT (the reference's :875 bug)
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "-s" || a == "--seed") p.seed = (uint32_t)atoi(next());
+        else if (a == "-m" || a == "--model") p.model = next();
+        else if (a == "-i" || a == "--inp") p.fname_inp = next();
+        else if (a == "-o" || a == "--out") p.image_out = next();
+        else if (a == "-t" || a == "--threads") p.n_threads = (uint32_t)atoi(next());
+        else if (a == "-k" || a == "--topk") p.topk = (uint32_t)atoi(next());
+        else if (a == "-cid" || a == "--camera_id") p.camera_id = (uint8_t)atoi(next());
+        else if (a == "-fa" || a == "--flash_attn") p.enable_flash_attn = true;
+        else if (a == "-c" || a == "--classify") p.classify = true;
+        else {
+            if (a != "-h" && a != "--help") fprintf(stderr, "error: unknown argument: %s\n", a.c_str());
+            print_usage(argv[0], p);
+            exit(0);
+        }
+    }
+    return true;
+}
+
+// binary PPM (P6, maxval 255) -> BGR interleaved like cv::imread
+bool read_ppm_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& h, int& w) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    auto token = [&](std::string& t) {
+        t.clear();
+        int c;
+        while ((c = fgetc(f)) != EOF) {
+            if (c == '#') { while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }
+            if (!isspace(c)) { t.push_back((char)c); break; }
+        }
+        while ((c = fgetc(f)) != EOF && !isspace(c)) t.push_back((char)c);
+        return !t.empty();
+    };
+    std::string t;
+    bool ok = token(t) && t == "P6" && token(t);
+    if (ok) { w = atoi(t.c_str()); ok = token(t); }
+    if (ok) { h = atoi(t.c_str()); ok = token(t) && atoi(t.c_str()) == 255 && w > 0 && h > 0; }
+    if (ok) {
+        std::vector<uint8_t> rgb((size_t)h * w * 3);
+        ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
+        bgr.resize(rgb.size());
+        for (size_t i = 0; ok && i < rgb.size(); i += 3) { bgr[i] = rgb[i + 2]; bgr[i + 1] = rgb[i + 1]; bgr[i + 2] = rgb[i]; }
+    }
+    fclose(f);
+    return ok;
+}
+
+bool write_ppm_from_bgr(const std::string& path, const std::vector<uint8_t>& bgr, int h, int w) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) return false;
+    fprintf(f, "P6\n%d %d\n255\n", w, h);
+    std::vector<uint8_t> rgb(bgr.size());
+    for (size_t i = 0; i < bgr.size(); i += 3) { rgb[i] = bgr[i + 2]; rgb[i + 1] = bgr[i + 1]; rgb[i + 2] = bgr[i]; }
+    const bool ok = fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+    fclose(f);
+    return ok;
+}
+
+// cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project (inference.cpp:76-81): the three leading eigenvectors of the H x H
+// covariance by power iteration with deflation, on the P x P Gram matrix when P < H.  Component signs: largest loading > 0.
+void pca3_project(const float* x, int P, int H, std::vector<float>& proj) {
+    std::vector<double> mean((size_t)H, 0.0);
+    for (int p = 0; p < P; ++p)
+        for (int j = 0; j < H; ++j) mean[(size_t)j] += x[(size_t)p * H + j];
+    for (auto& m : mean) m /= P;
+    std::vector<double> xc((size_t)P * H);
+    for (int p = 0; p < P; ++p)
+        for (int j = 0; j < H; ++j) xc[(size_t)p * H + j] = x[(size_t)p * H + j] - mean[(size_t)j];
+    std::vector<std::vector<double>> comps;
+    for (int c = 0; c < 3; ++c) {
+        std::vector<double> v((size_t)H), t((size_t)P);
+        for (int j = 0; j < H; ++j) v[(size_t)j] = std::sin(0.37 * (j + 1) * (c + 1)) + 0.01;  // fixed start: deterministic
+        std::vector<double> prev((size_t)H, 0.0);
+        for (int it = 0; it < 300; ++it) {
+            for (const auto& u : comps) {  // deflate: stay orthogonal to the components already found
+                double d = 0;
+                for (int j = 0; j < H; ++j) d += u[(size_t)j] * v[(size_t)j];
+                for (int j = 0; j < H; ++j) v[(size_t)j] -= d * u[(size_t)j];
+            }
+            for (int p = 0; p < P; ++p) {  // t = Xc v ; v = Xc^T t  (one step of power iteration on Xc^T Xc)
+                double d = 0;
+                for (int j = 0; j < H; ++j) d += xc[(size_t)p * H + j] * v[(size_t)j];
+                t[(size_t)p] = d;
+            }
+            std::fill(v.begin(), v.end(), 0.0);
+            for (int p = 0; p < P; ++p)
+                for (int j = 0; j < H; ++j) v[(size_t)j] += xc[(size_t)p * H + j] * t[(size_t)p];
+            double n = 0;
+            for (double a : v) n += a * a;
+            n = std::sqrt(n);
+            if (n == 0) break;
+            for (auto& a : v) a /= n;
+            double dot = 0;
+            for (int j = 0; j < H; ++j) dot += v[(size_t)j] * prev[(size_t)j];
+            if (std::fabs(dot) > 1.0 - 1e-12) break;  // converged
+            prev = v;
+        }
+        int big = 0;
+        for (int j = 1; j < H; ++j)
+            if (std::fabs(v[(size_t)j]) > std::fabs(v[(size_t)big])) big = j;
+        if (v[(size_t)big] < 0) for (auto& a : v) a = -a;
+        comps.push_back(v);
+    }
+    proj.assign((size_t)P * 3, 0.f);
+    for (int p = 0; p < P; ++p)
+        for (int c = 0; c < 3; ++c) {
+            double d = 0;
+            for (int j = 0; j < H; ++j) d += xc[(size_t)p * H + j] * comps[(size_t)c][(size_t)j];
+            proj[(size_t)p * 3 + c] = (float)d;
+        }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    dino_params params;
+    params.fname_inp = "../assets/tench.ppm";
+    params.image_out = "pca_visual.ppm";
+    if (!params_parse(argc, argv, params)) return 1;
+    fprintf(stderr, "%s: seed = %u\n", __func__, params.seed);
+    std::vector<uint8_t> bgr;
+    int h = 0, w = 0;
+    if (!read_ppm_bgr(params.fname_inp, bgr, h, w)) {
+        fprintf(stderr, "%s: failed to load image from '%s'\n", __func__, params.fname_inp.c_str());
+        return 1;
+    }
+    fprintf(stderr, "%s: loaded image '%s' (%d x %d)\n", __func__, params.fname_inp.c_str(), h, w);
+    dino_model model;
+    if (!dino_model_load(Size2i{w, h}, params.model, model, params)) {
+        fprintf(stderr, "%s: failed to load model from '%s'\n", __func__, params.model.c_str());
+        return 1;
+    }
+    // dino_classify_preprocess | dino_preprocess (dinov2.cpp:106-156) without OpenCV
+    const int ps = (int)model.hparams.patch_size;
+    int32_t oh = 0, ow = 0;
+    dinov2_hip_preprocess_size(params.classify ? 1 : 0, h, w, ps, &oh, &ow);
+    std::vector<float> pix((size_t)oh * ow * 3);
+    if (dinov2_hip_preprocess(params.classify ? 1 : 0, bgr.data(), h, w, ps, pix.data()) != DINOV2_HIP_OK) return 1;
+    Mat32f img;
+    img.rows = oh; img.cols = ow; img.channels = 3; img.data = pix.data();
+    fprintf(stderr, "%s: preprocessed image (%d x %d)\n", __func__, oh, ow);
+
+    const auto t0 = std::chrono::steady_clock::now();
+    std::unique_ptr<dino_output> output = dino_predict(model, img, params);
+    dinov2_hip_session_sync(model.default_session);
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "%s: graph computation took %lld ms\n", __func__,
+            (long long)std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+    if (!output) return 1;
+    if (output->patch_tokens) {
+        const Mat32f& tok = *output->patch_tokens;
+        std::vector<float> proj;
+        pca3_project(tok.data, tok.rows, tok.cols, proj);
+        float lo = proj[0], hi = proj[0];
+        for (float v : proj) { lo = std::min(lo, v); hi = std::max(hi, v); }
+        const int gr = oh / ps, gc = ow / ps;
+        std::vector<uint8_t> small((size_t)gr * gc * 3);
+        for (size_t i = 0; i < small.size(); ++i)
+            small[i] = (uint8_t)std::min(255.0f, std::max(0.0f, std::nearbyint(hi == lo ? 0.f : (proj[i] - lo) * (255.0f / (hi - lo)))));
+        std::vector<uint8_t> big((size_t)oh * ow * 3);
+        for (int y = 0; y < oh; ++y) {  // cv::resize(INTER_NEAREST): source index = floor(dst * scale)
+            const int sy = std::min((int)((double)y * gr / oh), gr - 1);
+            for (int x = 0; x < ow; ++x) {
+                const int sx = std::min((int)((double)x * gc / ow), gc - 1);
+                memcpy(&big[((size_t)y * ow + x) * 3], &small[((size_t)sy * gc + sx) * 3], 3);
+            }
+        }
+        if (write_ppm_from_bgr(params.image_out, big, oh, ow)) fprintf(stderr, "%s: Saved image to: %s\n", __func__, params.image_out.c_str());
+        else fprintf(stderr, "%s: failed to save image to '%s'\n", __func__, params.image_out.c_str());
+    }
+    return 0;
+}

@@ -1,5 +1,6 @@
 """the `inference` caller around the hot path (PCA visualisation + CLI), /root/reference/inference.cpp."""
 import os
+import sys
 from importlib import import_module
 
 import numpy as np
@@ -48,3 +49,54 @@ def test_cli_end_to_end(golden_dir, tmp_path, capsys):
     assert "Saved image to" in cap.err and "preprocessed image (70 x 84)" in cap.err
     assert np.asarray(Image.open(out)).shape == (70, 84, 3)
     assert inf.main(["inference", "-m", gguf, "-i", "/nonexistent.jpg"]) == 1
+
+
+def _build_cpp_inference(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "inference")
+    libdir = os.path.join(root, "dinov2.cpp_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "inference.cpp"), "-o", exe, os.path.join(libdir, "libdinov2_hip.so"),
+                           f"-Wl,-rpath,{libdir}"])
+    return exe
+
+
+def test_cpp_inference_builds_and_reports_errors(tmp_path):
+    """examples/inference.cpp (the reference's `inference` flow on the C++ shim, PPM instead of OpenCV codecs) builds with plain
+    g++; usage and failure paths behave like the reference (unknown flag -> usage + exit 0; unreadable image -> message + 1)."""
+    import subprocess
+    exe = _build_cpp_inference(tmp_path)
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 0 and "unknown argument" in r.stderr and "usage:" in r.stderr
+    r = subprocess.run([exe, "-i", "/nonexistent.ppm"], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to load image" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_inference_end_to_end(golden_dir, tmp_path):
+    """Same image through the C++ program and the Python CLI: identical top-k lines; the PCA map has the preprocessed size."""
+    import subprocess
+    exe = _build_cpp_inference(tmp_path)
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (60, 75, 3), dtype=np.uint8)
+    src, out = str(tmp_path / "in.ppm"), str(tmp_path / "pca.ppm")
+    with open(src, "wb") as f:
+        f.write(b"P6\n# a comment\n75 60\n255\n" + rgb.tobytes())
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    r = subprocess.run([exe, "-m", gguf, "-i", src, "-c", "-k", "3"], capture_output=True, text=True)
+    assert r.returncode == 0 and "graph computation took" in r.stderr and "preprocessed image (224 x 224)" in r.stderr, r.stderr
+    cpp_lines = [ln for ln in r.stdout.splitlines() if ln.startswith(" > ")]
+    assert len(cpp_lines) == 3
+    from PIL import Image
+    png = str(tmp_path / "in.png")
+    Image.fromarray(rgb).save(png)
+    py = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, '.'); from __graft_entry__ import load_package, PKG_NAME; "
+                         "load_package(); from importlib import import_module; "
+                         f"sys.exit(import_module(PKG_NAME + '.inference').main(['inference', '-m', r'{gguf}', '-i', r'{png}', '-c', '-k', '3']))"],
+                        capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert [ln for ln in py.stdout.splitlines() if ln.startswith(" > ")] == cpp_lines, py.stdout + py.stderr
+    r = subprocess.run([exe, "-m", gguf, "-i", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0 and "Saved image to" in r.stderr and "preprocessed image (70 x 84)" in r.stderr, r.stderr
+    hdr = open(out, "rb").read(15)
+    assert hdr.startswith(b"P6\n84 70\n255\n")
