@@ -47,15 +47,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (row >= rows) return;
     const int nv = H >> 2;
     const float4* xr = (const float4*)(x + (size_t)row * H);
-    float4 v[MAXV];
+    float4 v[MAXV], gw[MAXV], gb[MAXV];
     double sum = 0.0;
 #pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {  // all loads of the row first: x, and the affine parameters needed only at the end
         const int i = lane + 64 * j;
         if (i < nv) {
             v[j] = xr[i];
-            sum += (double)v[j].x + (double)v[j].y + (double)v[j].z + (double)v[j].w;
+            gw[j] = ((const float4*)w)[i];
+            gb[j] = ((const float4*)bta)[i];
         }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) sum += (double)v[j].x + (double)v[j].y + (double)v[j].z + (double)v[j].w;
     }
     sum = wave_sum_f64(sum);
     const float mean = (float)(sum / H);
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     for (int j = 0; j < MAXV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) {
-            const float4 ww = ((const float4*)w)[i], bb = ((const float4*)bta)[i];
+            const float4 ww = gw[j], bb = gb[j];
             float r0 = v[j].x * scale * ww.x + bb.x, r1 = v[j].y * scale * ww.y + bb.y;
             float r2 = v[j].z * scale * ww.z + bb.z, r3 = v[j].w * scale * ww.w + bb.w;
             // f32 result first, f16 rounding second (ggml rounds at the NEXT mul_mat): block v_fma_mix*_f16 fusion
