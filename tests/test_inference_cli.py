@@ -23,6 +23,20 @@ def test_pca_visual_matches_numpy_svd():
         assert abs(np.corrcoef(got[:, c], proj[:, c])[0, 1]) > 0.999
 
 
+def test_pca_visual_lanczos_path_matches_svd():
+    """H > 64 takes the three-eigenpair Lanczos solver: same components (up to sign) as a full SVD."""
+    inf = import_module(PKG_NAME + ".inference")
+    rng = np.random.default_rng(3)
+    P, H = 20 * 31, 256
+    base = rng.standard_normal((P, 3)) * np.array([9.0, 5.0, 2.5]) @ rng.standard_normal((3, H)) + rng.standard_normal((P, H)) * 0.05
+    vis = inf.pca_visual(base.astype(np.float32), 20, 31, 20 * 14, 31 * 14)
+    xc = base - base.mean(0)
+    proj = xc @ np.linalg.svd(xc, full_matrices=False)[2][:3].T
+    got = vis[::14, ::14].reshape(P, 3).astype(np.float64)
+    for c in range(3):
+        assert abs(np.corrcoef(got[:, c], proj[:, c])[0, 1]) > 0.999
+
+
 def test_cli_flag_parsing(api):
     inf = import_module(PKG_NAME + ".inference")
     p = api.dino_params()
