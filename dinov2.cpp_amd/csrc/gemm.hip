@@ -304,7 +304,9 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
         return !e || atoi(e) != 0;
     }();
-    const bool big_ok = epi != EPI_PATCH && a.P != -1 && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
+    // (the patch-embed epilogue maps row -> (image, patch): no row splits for it; a.P == -1 marks the tail of a split)
+    const bool is_patch = epi == EPI_PATCH;
+    const bool big_ok = (is_patch || a.P != -1) && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
     if (big_ok) {
         const int ntn = a.N / 256;
         const long t256 = (long)ntn * ((a.M + 255) / 256), t192 = (long)ntn * ((a.M + 191) / 192);
@@ -323,7 +325,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const int panels1 = (int)(R * 256 / ntn);
         const int M1 = panels1 * 256;
         GemmArgs a1 = a, a2 = a;
-        if (split_ok && forced != 256 && R >= 1 && M1 > 0 && M1 < a.M) {
+        if (split_ok && !is_patch && forced != 256 && R >= 1 && M1 > 0 && M1 < a.M) {
             const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
             a1.M = M1;
             a2.M = a.M - M1;
@@ -335,6 +337,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
             if (costC < best - 0.02) { plan = 'C'; best = costC; }
             if (costD < best - 0.02) { plan = 'D'; best = costD; }
         }
+        if (is_patch) plan = (plan == 'E' || t192 < 192) ? 'E' : 'B';  // only the 192-row instantiation exists for this epilogue
         switch (plan) {
             case 'A': return launch_gemm2(dt, epi, a, st);
             case 'B': return launch_gemm2_192(dt, epi, a, st);

@@ -511,7 +511,10 @@ static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((gemm2_kernel<T, E, XREP>), grid, block, lds, st, a); \
         break;
     switch (epi) {
-        case EPI_PATCH: return hipErrorInvalidValue;  // patch-embed (0.16 % of FLOPs) stays on the 128x128 kernel
+        case EPI_PATCH:  // the 256-row instantiation spills (the pos-embed prefetch on top of 128 accumulators); 192-row does not
+            if (XREP == 4) return hipErrorInvalidValue;
+            hipLaunchKernelGGL((gemm2_kernel<T, EPI_PATCH, 3>), grid, block, lds, st, a);
+            break;
         DINO_L2(EPI_QKV)
         DINO_L2(EPI_RESID)
         DINO_L2(EPI_GELU)
@@ -564,6 +567,9 @@ static hipError_t attr2_t() {
 #define DINO_A2(E)                                                                  \
     if (e == hipSuccess)                                                            \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<T, E, XREP>), \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess && XREP == 3)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<T, EPI_PATCH, 3>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DINO_A2(EPI_QKV)
     DINO_A2(EPI_RESID)
