@@ -291,3 +291,35 @@ print("GRAPH_OK")
     out = subprocess.run([sys.executable, "-c", code, os.path.join(golden_dir, "tiny_gelu_reg4.gguf")], cwd=root, env=env,
                          capture_output=True, text=True, timeout=600)
     assert "GRAPH_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_two_sessions_on_two_threads(api, golden_dir):
+    """include/dinov2_hip.h: a model is immutable and may be shared by any number of sessions; one session per host thread.
+    Two threads, each with its own session (own stream + workspace), run different inputs concurrently (ctypes releases the
+    GIL inside the C calls); every result must equal the single-threaded one bit for bit."""
+    import threading
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    model = api.Model(gguf, classify=True)
+    rng = np.random.default_rng(21)
+    inputs = [rng.standard_normal((3, 3, 70, 98)).astype(np.float32), rng.standard_normal((2, 3, 154, 70)).astype(np.float32)]
+    ref = [api.Session(model).predict(x, classify=True)["logits"] for x in inputs]
+    out = [[None] * 20, [None] * 20]
+    errs = []
+
+    def worker(k):
+        try:
+            sess = api.Session(model)
+            for i in range(20):
+                out[k][i] = sess.predict(inputs[k], classify=True)["logits"]
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for k in range(2):
+        for i in range(20):
+            assert np.array_equal(out[k][i], ref[k]), (k, i)
