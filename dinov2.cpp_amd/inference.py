@@ -22,6 +22,15 @@ def pca_visual(patch_tokens: np.ndarray, rows: int, cols: int, out_h: int, out_w
     """cv::PCA(DATA_AS_ROW, 3) + project + normalize(0, 255, NORM_MINMAX, CV_8U) + reshape + resize(INTER_NEAREST)
     (inference.cpp:76-92).  Returns uint8 [out_h, out_w, 3].  Eigenvector signs are a free choice in any PCA; here each
     component is oriented so that its largest-magnitude loading is positive."""
+    try:  # a 2 170 x 1 024 problem spread over hundreds of BLAS threads is slower than over eight
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=8):
+            return _pca_visual(patch_tokens, rows, cols, out_h, out_w)
+    except ImportError:
+        return _pca_visual(patch_tokens, rows, cols, out_h, out_w)
+
+
+def _pca_visual(patch_tokens, rows, cols, out_h, out_w):
     x = patch_tokens.astype(np.float32)
     mean = x.mean(0, keepdims=True, dtype=np.float64).astype(np.float32)
     xc = x - mean
@@ -30,7 +39,7 @@ def pca_visual(patch_tokens: np.ndarray, rows: int, cols: int, out_h: int, out_w
     if cov.shape[0] > 64:
         try:  # three leading eigenpairs only (Lanczos): ~10 ms at H = 1024 where numpy's full eigh takes ~400 ms
             from scipy.sparse.linalg import eigsh
-            w, v = eigsh(cov, k=3, which="LA", v0=np.ones(cov.shape[0]), tol=1e-10)
+            w, v = eigsh(cov, k=3, which="LA", v0=np.ones(cov.shape[0]), tol=1e-7)
             comp = v[:, np.argsort(-w)].T.copy()
         except Exception:
             comp = None
@@ -40,7 +49,7 @@ def pca_visual(patch_tokens: np.ndarray, rows: int, cols: int, out_h: int, out_w
     for c in comp:
         if c[np.abs(c).argmax()] < 0:
             c *= -1
-    proj = (xc @ comp.T).astype(np.float32)                      # [P, 3]
+    proj = xc @ comp.T.astype(np.float32)                        # [P, 3]; same dtype on both sides keeps this a BLAS call
     lo, hi = float(proj.min()), float(proj.max())
     norm = np.zeros_like(proj) if hi == lo else (proj - lo) * (255.0 / (hi - lo))
     img = np.rint(norm).clip(0, 255).astype(np.uint8).reshape(rows, cols, 3)
