@@ -348,3 +348,44 @@ def test_gemm_swiglu_small_and_large_m_agree_bit_for_bit(api):
     _gemm(api, F16, EPI_SWIGLU, np.ascontiguousarray(np.tile(X, (32, 1))), W, bias, None, big, 32 * T, 2 * F, K, F)
     assert np.isfinite(small).all()
     assert np.array_equal(big[:T], small) and np.array_equal(big[-T:], small)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_gemm_random_shapes_all_plans(api, seed):
+    """Random (M, N, K, epilogue) over the whole range the dispatcher sees -- one image to 50 images, every hidden size of the
+    DINOv2 family, odd and even K / 64 -- so that every kernel plan (256-row, 192-row, mixed, small-tile tail, small-tile only)
+    and every ragged edge is exercised against a float32 reference; whole output checked."""
+    rng = np.random.default_rng(1000 + seed)
+    M = int(rng.choice([1, 37, 1374, 2748, 4122, 5496, 10992, 21984, 32976, 43968, 51000, 68700])) + int(rng.integers(0, 3)) * int(rng.integers(0, 200))
+    N = int(rng.choice([256, 384, 768, 1024, 1152, 1536, 2304, 3072, 4096]))
+    K = int(rng.choice([128, 192, 384, 640, 768, 1024, 1536]))
+    epi = [EPI_PLAIN, EPI_RESID, EPI_GELU, EPI_QKV][seed % 4]
+    if M * N * K > 6e10:
+        M = max(1, int(6e10 / (N * K)))
+    A = _round(rng.standard_normal((M, K)), F16)
+    W = _round(rng.standard_normal((N, K)) * 0.06, F16)
+    bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    ref = A @ W.T + bias
+    if epi == EPI_PLAIN:
+        out = np.full((M, N), np.nan, np.float32)
+        tol = 3e-4
+    elif epi == EPI_RESID:
+        x0 = rng.standard_normal((M, N)).astype(np.float32)
+        out = x0.copy()
+        ref = x0 + aux * ref
+        tol = 6e-4
+    elif epi == EPI_GELU:
+        out = np.zeros((M, N), np.float32)
+        xr = ref.astype(np.float16).astype(np.float64)
+        ref = (0.5 * xr * (1 + np.tanh(0.79788456080286535587989211986876 * xr * (1 + 0.044715 * xr * xr)))).astype(np.float32)
+        ref = ref.astype(np.float16).astype(np.float32)
+        tol = 2e-3
+    else:
+        out = np.zeros((M, N), np.float32)
+        ref[:, :N // 2] *= 0.125
+        ref = _round(ref, F16)
+        tol = 2e-3
+    _gemm(api, F16, epi, A, W, bias, aux, out, M, N, K, N, qcols=N // 2, qscale=0.125)
+    assert np.isfinite(out).all()
+    bad = np.abs(out - ref) > tol * np.maximum(1.0, np.abs(ref))
+    assert bad.mean() < (2e-4 if epi in (EPI_GELU, EPI_QKV) else 1e-7), f"M={M} N={N} K={K}: {bad.sum()} mismatches, first at {np.argwhere(bad)[:4]}"
