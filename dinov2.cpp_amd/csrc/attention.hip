@@ -188,12 +188,15 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
     constexpr float THR = LOG2 ? 8.0f : 5.5f;
 
     const int ntiles = (Ttok + KT - 1) / KT;
+    // wave-uniform: the last query block of a head is ragged (1 374 tokens = 10 blocks + 94 queries -> one idle wave of 44)
+    const bool idle_wave = __builtin_amdgcn_readfirstlane(qb * (NWV * 32) + wid * 32) >= Ttok;
     auto tile = [&](int jt, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         DINO_TS(0)
         __syncthreads();
         DINO_TS(1)
         if (!MASKED) stage((jt + 1) & 1, jt + 1);
+        if (idle_wave) return;  // a wave whose 32 queries all lie past the last token only helps with staging and barriers
         const char* sK = smem + (jt & 1) * 2 * TILEB;
         const char* sV = sK + TILEB;
 
