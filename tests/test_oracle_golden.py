@@ -94,3 +94,54 @@ def test_oracle_thread_count_invariance(golden_dir):
     a = m.forward(g["img_42x42"], classify=True, nthreads=1)["logits"]
     b = m.forward(g["img_42x42"], classify=True, nthreads=4)["logits"]
     assert np.array_equal(a, b)
+
+
+def test_oracle_matches_hf_at_vit_s_scale(tmp_path):
+    """The committed fixtures are tiny (H = 128, 2 layers).  This one pins the oracle at the real ViT-S/14 + 4 registers
+    geometry (H = 384, 12 layers, 6 heads, 518-pixel pos-embed table, 224 x 224 input: 37 -> 16 bicubic) against a live,
+    seeded HuggingFace model: nothing big is committed, the weights are rebuilt on the fly and go through the repo's own
+    HF -> GGUF converter.  Needs transformers (authoring container / same image on the GPU box); skipped where absent."""
+    pytest.importorskip("transformers")
+    import importlib.util
+    import torch
+    from importlib import import_module
+    from __graft_entry__ import PKG_NAME
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)  # patches HF's pos-embed interpolation to the reference's (no antialias)
+    from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersForImageClassification
+    torch.manual_seed(5)
+    cfg = Dinov2WithRegistersConfig(hidden_size=384, num_hidden_layers=12, num_attention_heads=6, mlp_ratio=4,
+                                    hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6, image_size=518, patch_size=14,
+                                    num_register_tokens=4, num_labels=10, layerscale_value=1.0)
+    model = Dinov2WithRegistersForImageClassification(cfg).eval()
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():  # non-trivial values everywhere (default init has zero biases and unit norms); weights f16-exact
+        for pn, p in model.named_parameters():
+            if pn.endswith("lambda1"):
+                p.copy_(0.2 + 0.1 * torch.randn(p.shape, generator=g))
+            elif "norm" in pn and pn.endswith("weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif p.ndim >= 2 and "embeddings" not in pn or "projection.weight" in pn:
+                p.copy_((0.04 * torch.randn(p.shape, generator=g)).half().float())
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    conv = import_module(PKG_NAME + ".convert")
+    path = str(tmp_path / "vits.gguf")
+    conv.convert_state_dict({k: v.detach().numpy() for k, v in model.state_dict().items()}, model.config.to_dict(), path)
+    img = torch.randn(3, 224, 224, generator=g).numpy()
+    with torch.no_grad():
+        out = model.dinov2_with_registers(torch.from_numpy(img)[None], output_hidden_states=True)
+        hidden = torch.stack([h[0] for h in out.hidden_states]).numpy()
+        final = out.last_hidden_state[0].numpy()
+    m = OracleModel(path, act_round=0, gelu_f16_lut=False)
+    m.set(conv_round=0)
+    o = m.forward(img, classify=True, hidden=True)
+    assert o["hidden"].shape == hidden.shape == (13, 1 + 4 + 256, 384)
+    scale = max(1.0, float(np.abs(hidden).max()))
+    assert np.abs(o["hidden"] - hidden).max() < 5e-5 * scale
+    assert np.abs(o["cls"] - final[0]).max() < 1e-4 and np.abs(o["patch_tokens"] - final[1:]).max() < 1e-4
+    # and with ggml's roundings switched on the result stays within the documented envelope of the f32 one
+    r = OracleModel(path).forward(img, classify=True)
+    assert np.abs(r["patch_tokens"] - final[1:]).max() < 2e-2
