@@ -233,17 +233,24 @@ def main():
         from oracle.oracle import OracleModel
         ora = OracleModel(path)
         img1 = imgs[0].cpu().numpy()
-        cores = os.cpu_count() or 1
-        t0 = time.perf_counter()
-        exp = ora.forward(img1, classify=True)
-        cpu_s = time.perf_counter() - t0
-        got = logits[0].cpu().numpy() if B == 1 else None
+        # the box may give the container far fewer CPUs than os.cpu_count() says (256 threads measured 20-40x SLOWER than
+        # 16): time a few team sizes on the same image and report the best -- a CPU baseline should not be handicapped
+        best_s, cores, exp = None, None, None
+        for nt in (8, 16, 32):
+            t0 = time.perf_counter()
+            e = ora.forward(img1, classify=True, nthreads=nt)
+            dt_cpu = time.perf_counter() - t0
+            if best_s is None or dt_cpu < best_s:
+                best_s, cores, exp = dt_cpu, nt, e
+        cpu_s = best_s
+        got = None
         # parity spot-check of the timed configuration itself (image 0 of the last step)
         step()
         sess.sync()
         dl = float(np.abs(logits[0].cpu().numpy() - exp["logits"]).max())
         cpu = {"value": round(1.0 / cpu_s, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-               "sample": f"1 image, {args.model} 518x518 batch 1, full predict, OpenMP {cores} threads",
+               "sample": f"1 image, {args.model} 518x518 batch 1, full predict, best of OpenMP teams of 8 / 16 / 32 threads "
+                         f"(host reports {os.cpu_count()} CPUs)",
                "max_abs_logit_diff_vs_gpu": round(dl, 6)}
         del got
 

@@ -160,6 +160,9 @@ class OracleModel:
 
     def forward(self, img_chw: np.ndarray, classify: bool = False, hidden: bool = False, nthreads: int = 0) -> dict:
         """img_chw: planar RGB f32 [3, H, W] (the "input" tensor of dinov2.cpp:629-631)."""
+        if nthreads <= 0:  # OpenMP's default team = every CPU the host reports; containers are often given far fewer (256
+            # threads measured 20-40x slower than 16 on the GPU box), so default to a modest team unless OMP_NUM_THREADS says otherwise
+            nthreads = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(16, os.cpu_count() or 1)
         img = np.ascontiguousarray(img_chw, dtype=np.float32)
         assert img.ndim == 3 and img.shape[0] == 3
         _, hh, ww = img.shape
