@@ -323,3 +323,24 @@ def test_two_sessions_on_two_threads(api, golden_dir):
     for k in range(2):
         for i in range(20):
             assert np.array_equal(out[k][i], ref[k]), (k, i)
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_random_shapes_vs_oracle(api, golden_dir, name):
+    """Twenty random (batch, height, width, classify) per fixture -- every patch-grid shape from 1 x 1 to 25 x 25, one session
+    re-carving its workspace each time -- one image of each batch against the oracle."""
+    gguf = os.path.join(golden_dir, name + ".gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    ora = OracleModel(gguf)
+    rng = np.random.default_rng(sum(map(ord, name)))
+    for _ in range(20):
+        B, h, w = int(rng.integers(1, 10)), 14 * int(rng.integers(1, 26)), 14 * int(rng.integers(1, 26))
+        classify = bool(rng.integers(0, 2))
+        x = rng.standard_normal((B, 3, h, w)).astype(np.float32)
+        got = sess.predict(x, classify=classify)
+        b = int(rng.integers(0, B))
+        exp = ora.forward(x[b], classify=classify)
+        assert np.isfinite(got["patch_tokens"]).all(), (B, h, w)
+        assert _rel(got["patch_tokens"][b], exp["patch_tokens"]) <= 5e-3, (B, h, w, classify)
+        if classify:
+            assert _rel(got["logits"][b], exp["logits"]) <= 1e-3, (B, h, w)
