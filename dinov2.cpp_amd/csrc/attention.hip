@@ -65,6 +65,20 @@ static __device__ __forceinline__ float max_halves(float m) {
     asm volatile("s_nop 4\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 4" : "+v"(a), "+v"(b));
     return max3f(a, b, b);
 }
+// First MFMA of a score chain: accumulator input C (the -m_run tuple) and result D in DIFFERENT registers.  Written as asm
+// because hipcc, given the builtin, copies C into D's registers first (8 v_mov_b64 per key tile and chain pair).  The early
+// clobber keeps D off the inputs; 16-pass MFMA results are consumed only by further MFMAs (hardware-interlocked) or after
+// mfma_settle().
+template <typename V8>
+static __device__ __forceinline__ f32x16 mfma32_c(V8 a, V8 b, const f32x16& c) {
+    f32x16 d;
+    if constexpr (sizeof(((V8*)nullptr)[0][0]) == 2 && __is_same(V8, f16x8))
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // hipcc's hazard recogniser pads an MFMA result -> VALU read with the required wait states only when it can see the reader;
 // the asm v_max3 below is opaque to it, so reading fresh accumulators raced with the matrix pipeline (nondeterministic
 // scores, found by the batch-permutation test).  19 wait states cover a 16-pass MFMA; tied operands order the block after
@@ -207,7 +221,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const vec8 kf = *(const vec8*)(sK + kaddr[ks] + kb * 32 * ROWB);
-                s[kb] = E::mfma32(kf, qf[ks], ks == 0 ? negm : s[kb]);
+                if (ks == 0) s[kb] = mfma32_c(kf, qf[0], negm);  // D != C: no copy of the 16 -m_run registers per chain
+                else s[kb] = E::mfma32(kf, qf[ks], s[kb]);
             }
         }
         DINO_TS(2)
