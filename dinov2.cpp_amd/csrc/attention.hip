@@ -147,7 +147,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
     const int srow = lane >> 3;
     constexpr int SI = 8 / NWV;
     const char* kbase = base + ((size_t)h * 64 + H) * 2;
-    const unsigned rowb = (unsigned)H3 * 2u, vdelta = (unsigned)H * 2u;
+    const unsigned rowb = (unsigned)H3 * 2u;
+    const char* vbase = kbase + (size_t)H * 2;
     unsigned stoff[SI], stmax[SI];
 #pragma unroll
     for (int j = 0; j < SI; ++j) {
@@ -163,8 +164,8 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
         for (int j = 0; j < SI; ++j) {
             const unsigned off = stoff[j] < stmax[j] ? stoff[j] : stmax[j];
             stoff[j] += KT * rowb;
-            glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);
-            glds16(kbase + off + vdelta, sV + (j * NWV + wid) * 8 * ROWB);
+            glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);  // uniform base + 32-bit lane offset: scalar-base loads
+            glds16(vbase + off, sV + (j * NWV + wid) * 8 * ROWB);
         }
     };
 
