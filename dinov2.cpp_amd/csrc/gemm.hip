@@ -304,9 +304,9 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
         return !e || atoi(e) != 0;
     }();
-    // (the patch-embed epilogue maps row -> (image, patch): no row splits for it; a.P == -1 marks the tail of a split)
+    // (the patch-embed epilogue maps row -> (image, patch): no row splits for it)
     const bool is_patch = epi == EPI_PATCH;
-    const bool big_ok = (is_patch || a.P != -1) && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
+    const bool big_ok = !a.small_only && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
     if (big_ok) {
         const int ntn = a.N / 256;
         const long t256 = (long)ntn * ((a.M + 255) / 256), t192 = (long)ntn * ((a.M + 191) / 192);
@@ -345,7 +345,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
             case 'D': {
                 const hipError_t e = launch_gemm2(dt, epi, a1, st);
                 if (e != hipSuccess) return e;
-                a2.P = -1;  // marks "tail of a split": go straight to the small-tile kernel below
+                a2.small_only = 1;  // the tail of a split goes straight to the small-tile kernel below
                 return launch_gemm(dt, epi, a2, st);
             }
             default: break;  // 'E'
