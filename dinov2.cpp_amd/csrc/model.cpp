@@ -563,7 +563,6 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
     const int H = (int)m->hp.hidden_size, F = (int)m->hp.ffn_hidden, R = (int)m->hp.num_register_tokens;
     const int nh = (int)m->hp.num_attention_heads, ps = (int)m->hp.patch_size;
     const Dims d = dims_of(m, B, h, w);
-    const int h0 = h / ps, w0 = w / ps;
     hipStream_t st = s->stream;
     const DType dt = m->dt;
 

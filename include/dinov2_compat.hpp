@@ -186,6 +186,16 @@ inline std::unique_ptr<dino_output> dino_predict(const dino_model& model, const 
     return output;
 }
 
+// dinov2.h:118 / dinov2.cpp:355-453
+inline bool dino_model_quantize(const std::string& fname_inp, const std::string& fname_out, int itype) {
+    char err[512] = {0};
+    if (dinov2_hip_quantize(fname_inp.c_str(), fname_out.c_str(), itype, err, sizeof err) != DINOV2_HIP_OK) {
+        fprintf(stderr, "%s: %s\n", __func__, err);
+        return false;
+    }
+    return true;
+}
+
 #ifdef DINOV2_WITH_OPENCV
 inline bool dino_model_load(cv::Size sz, const std::string& fname, dino_model& model, const dino_params& params) {
     return dino_model_load(Size2i{sz.width, sz.height}, fname, model, params);

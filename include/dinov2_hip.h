@@ -133,6 +133,10 @@ int dinov2_hip_predict(dinov2_hip_session *session, const dinov2_hip_input *in, 
 int dinov2_hip_preprocess_size(int32_t mode, int32_t height, int32_t width, int32_t patch, int32_t *out_h, int32_t *out_w);
 int dinov2_hip_preprocess(int32_t mode, const uint8_t *bgr, int32_t height, int32_t width, int32_t patch, float *out);
 
+/* -- quantise a GGUF (replaces dino_model_quantize, dinov2.h:118 / dinov2.cpp:355-453).  Host only.
+ *    itype: ggml type id 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0.  2-D tensors named `*weight` are re-encoded, the rest copied. */
+int dinov2_hip_quantize(const char *fname_inp, const char *fname_out, int32_t itype, char *err, size_t errlen);
+
 /* Host helper, exposed for parity tests: interpolate_pos_embed (dinov2.h:101-103 / dinov2.cpp:159-225).
  * out: [(1 + h_new*w_new), H] f32. */
 int dinov2_hip_interpolate_pos_embed(const dinov2_hip_model *model, int32_t h_new, int32_t w_new, float *out);

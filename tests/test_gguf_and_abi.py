@@ -6,9 +6,11 @@ import struct
 import subprocess
 
 import numpy as np
+from importlib import import_module
 import pytest
 
 from oracle import gguf_np as G
+from __graft_entry__ import PKG_NAME
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -260,3 +262,34 @@ def test_loader_survives_corrupted_files(api, golden_dir, tmp_path):
             assert str(e)  # every failure carries a message
             statuses.add(e.status)
     assert 2 in statuses  # format errors were exercised
+
+
+@pytest.mark.parametrize("itype", [2, 3, 6, 7, 8])
+def test_native_quantize_equals_python_tool(api, pkg, golden_dir, tmp_path, itype):
+    """dinov2_hip_quantize (C++, behind the C-ABI and the shim's dino_model_quantize) writes the same bytes as the numpy tool
+    whose quantisers the oracle's dequantisers are pinned against -- for an f16 fixture and for a model holding f32 weights."""
+    import ctypes as C
+    q = import_module(PKG_NAME + ".quantize")
+    srcs = [os.path.join(golden_dir, "tiny_swiglu_reg4.gguf")]
+    f32 = str(tmp_path / "f32.gguf")
+    w = pkg.gguf_writer.GGUFWriter()
+    rng = np.random.default_rng(itype)
+    w.add_uint32("ftype", 0)
+    w.add_string("note", "f32 weights")
+    w.add_tensor("a.weight", rng.standard_normal((48, 64)).astype(np.float32) * 3)
+    w.add_tensor("a.bias", rng.standard_normal(48).astype(np.float32))
+    w.add_tensor("embeddings.patch_embeddings.projection.weight", rng.standard_normal((8, 3, 14, 14)).astype(np.float16))
+    w.add_tensor("z.weight", np.zeros((4, 32), np.float32))  # all-zero blocks: d = 0 path
+    w.write(f32)
+    srcs.append(f32)
+    for k, src in enumerate(srcs):
+        a, b = str(tmp_path / f"py{k}.gguf"), str(tmp_path / f"cc{k}.gguf")
+        assert q.dino_model_quantize(src, a, itype)
+        err = C.create_string_buffer(256)
+        fn = api.lib().dinov2_hip_quantize
+        fn.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, C.c_char_p, C.c_size_t]
+        assert fn(src.encode(), b.encode(), itype, err, 256) == 0, err.value
+        assert open(a, "rb").read() == open(b, "rb").read()
+    err = C.create_string_buffer(256)
+    assert api.lib().dinov2_hip_quantize(srcs[0].encode(), str(tmp_path / "x.gguf").encode(), 5, err, 256) == 4  # invalid type
+    assert api.lib().dinov2_hip_quantize(b"/nonexistent.gguf", str(tmp_path / "x.gguf").encode(), 8, err, 256) == 1
