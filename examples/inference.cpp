@@ -19,40 +19,6 @@
 
 namespace {
 
-void print_usage(const char* prog, const dino_params& p) {  // dinov2.cpp:840-863
-    fprintf(stderr, "usage: %s [options]\n\noptions:\n", prog);
-    fprintf(stderr, "  -h, --help              show this help message and exit\n");
-    fprintf(stderr, "  -m FNAME, --model       model path (default: %s)\n", p.model.c_str());
-    fprintf(stderr, "  -i FNAME, --inp         input file, binary PPM (default: %s)\n", p.fname_inp.c_str());
-    fprintf(stderr, "  -o FNAME, --out         output file for backbone PCA features (default: %s)\n", p.image_out.c_str());
-    fprintf(stderr, "  -k N, --topk            top k classes to print (default: %u)\n", p.topk);
-    fprintf(stderr, "  -t N, --threads         number of threads to use during computation (default: %u)\n", p.n_threads);
-    fprintf(stderr, "  -c, --classify          whether to classify the image or get backbone PCA features (default: %d)\n", (int)p.classify);
-    fprintf(stderr, "  -fa, --flash_attn          whether to enable flash_attn, less accurate (default: %d)\n\n", (int)p.enable_flash_attn);
-}
-
-bool params_parse(int argc, char** argv, dino_params& p) {  // dinov2.cpp:865-898; -o sets the OUTPUT (the reference's :875 bug)
-    for (int i = 1; i < argc; ++i) {
-        const std::string a = argv[i];
-        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
-        if (a == "-s" || a == "--seed") p.seed = (uint32_t)atoi(next());
-        else if (a == "-m" || a == "--model") p.model = next();
-        else if (a == "-i" || a == "--inp") p.fname_inp = next();
-        else if (a == "-o" || a == "--out") p.image_out = next();
-        else if (a == "-t" || a == "--threads") p.n_threads = (uint32_t)atoi(next());
-        else if (a == "-k" || a == "--topk") p.topk = (uint32_t)atoi(next());
-        else if (a == "-cid" || a == "--camera_id") p.camera_id = (uint8_t)atoi(next());
-        else if (a == "-fa" || a == "--flash_attn") p.enable_flash_attn = true;
-        else if (a == "-c" || a == "--classify") p.classify = true;
-        else {
-            if (a != "-h" && a != "--help") fprintf(stderr, "error: unknown argument: %s\n", a.c_str());
-            print_usage(argv[0], p);
-            exit(0);
-        }
-    }
-    return true;
-}
-
 // binary PPM (P6, maxval 255) -> BGR interleaved like cv::imread
 bool read_ppm_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& h, int& w) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -152,7 +118,7 @@ int main(int argc, char** argv) {
     dino_params params;
     params.fname_inp = "../assets/tench.ppm";
     params.image_out = "pca_visual.ppm";
-    if (!params_parse(argc, argv, params)) return 1;
+    if (!dino_params_parse(argc, argv, params)) return 1;
     fprintf(stderr, "%s: seed = %u\n", __func__, params.seed);
     std::vector<uint8_t> bgr;
     int h = 0, w = 0;
@@ -168,12 +134,11 @@ int main(int argc, char** argv) {
     }
     // dino_classify_preprocess | dino_preprocess (dinov2.cpp:106-156) without OpenCV
     const int ps = (int)model.hparams.patch_size;
-    int32_t oh = 0, ow = 0;
-    dinov2_hip_preprocess_size(params.classify ? 1 : 0, h, w, ps, &oh, &ow);
-    std::vector<float> pix((size_t)oh * ow * 3);
-    if (dinov2_hip_preprocess(params.classify ? 1 : 0, bgr.data(), h, w, ps, pix.data()) != DINOV2_HIP_OK) return 1;
-    Mat32f img;
-    img.rows = oh; img.cols = ow; img.channels = 3; img.data = pix.data();
+    Mat8u raw;
+    raw.rows = h; raw.cols = w; raw.data = bgr.data();
+    Mat32f img = params.classify ? dino_classify_preprocess(raw, Size2i{w, h}, model.hparams) : dino_preprocess(raw, Size2i{w, h}, model.hparams);
+    if (!img.data) return 1;
+    const int oh = img.rows, ow = img.cols;
     fprintf(stderr, "%s: preprocessed image (%d x %d)\n", __func__, oh, ow);
 
     const auto t0 = std::chrono::steady_clock::now();

@@ -18,12 +18,18 @@
 //        const cv::Mat&, const dino_params&, ggml_gallocr_t)           const dino_model&, const Mat32f&,
 //                                             dinov2.h:111-112         const dino_params&, dinov2_hip_session*)
 //
+//   dino_preprocess / dino_classify_preprocess dinov2.h:93-96      same names, Mat8u in / Mat32f out (no OpenCV)
+//   interpolate_pos_embed         dinov2.h:101-103                same name, takes the model instead of the raw table
+//   print_usage / dino_params_parse  dinov2.h:114-116             same
+//   dino_model_quantize           dinov2.h:118                    same
+//
 // `Mat32f` is layout-compatible with a continuous CV_32FC3 cv::Mat; define DINOV2_WITH_OPENCV before including to
 // get cv::Mat / cv::Size overloads.
 #pragma once
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <optional>
@@ -184,6 +190,81 @@ inline std::unique_ptr<dino_output> dino_predict(const dino_model& model, const 
         output->patch_tokens = m;
     }
     return output;
+}
+
+// 8-bit BGR interleaved image view, as cv::imread returns it (CV_8UC3, continuous)
+struct Mat8u {
+    int rows = 0, cols = 0;
+    const uint8_t* data = nullptr;
+    Size2i size() const { return Size2i{cols, rows}; }
+};
+
+namespace dinov2_compat_detail {
+inline Mat32f preprocess(int mode, const Mat8u& img, const dino_hparams& hp) {
+    Mat32f out;
+    int32_t oh = 0, ow = 0;
+    if (!img.data || dinov2_hip_preprocess_size(mode, img.rows, img.cols, (int32_t)hp.patch_size, &oh, &ow) != DINOV2_HIP_OK) return out;
+    out.rows = oh; out.cols = ow; out.channels = 3;
+    out.owner = std::make_shared<std::vector<float>>((size_t)oh * ow * 3);
+    out.data = out.owner->data();
+    if (dinov2_hip_preprocess(mode, img.data, img.rows, img.cols, (int32_t)hp.patch_size, out.data) != DINOV2_HIP_OK) out = Mat32f{};
+    return out;
+}
+}  // namespace dinov2_compat_detail
+
+// dinov2.h:93-96 / dinov2.cpp:106-156 (img_size is unused there as well): 256 x 256 squash + centre crop 224 | resize to the
+// next multiple of the patch size plus one patch; /255, bicubic, (c - mean) / std with the reference's BGR <-> mean indexing
+inline Mat32f dino_classify_preprocess(const Mat8u& img, Size2i /*img_size*/, const dino_hparams& params) {
+    return dinov2_compat_detail::preprocess(1, img, params);
+}
+inline Mat32f dino_preprocess(const Mat8u& img, Size2i /*img_size*/, const dino_hparams& params) {
+    return dinov2_compat_detail::preprocess(0, img, params);
+}
+
+// dinov2.h:101-103 / dinov2.cpp:159-225.  The reference passes the raw table pointer; here the model owns it.
+// Returns [(1 + h*w), hidden] for an image of img_size (multiples of the patch size).
+inline std::vector<float> interpolate_pos_embed(Size2i img_size, const dino_model& model) {
+    const int ps = (int)model.hparams.patch_size;
+    const int h = img_size.height / ps, w = img_size.width / ps;
+    std::vector<float> out((size_t)(1 + h * w) * model.hparams.hidden_size);
+    if (dinov2_hip_interpolate_pos_embed(model.handle, h, w, out.data()) != DINOV2_HIP_OK) out.clear();
+    return out;
+}
+
+// dinov2.h:114 / dinov2.cpp:840-863
+inline void print_usage(int /*argc*/, char** argv, const dino_params& params) {
+    fprintf(stderr, "usage: %s [options]\n\noptions:\n", argv[0]);
+    fprintf(stderr, "  -h, --help              show this help message and exit\n");
+    fprintf(stderr, "  -m FNAME, --model       model path (default: %s)\n", params.model.c_str());
+    fprintf(stderr, "  -i FNAME, --inp         input file (default: %s)\n", params.fname_inp.c_str());
+    fprintf(stderr, "  -o FNAME, --out         output file for backbone PCA features (default: %s)\n", params.image_out.c_str());
+    fprintf(stderr, "  -k N, --topk            top k classes to print (default: %u)\n", params.topk);
+    fprintf(stderr, "  -t N, --threads         number of threads to use during computation (default: %u)\n", params.n_threads);
+    fprintf(stderr, "  -c, --classify          whether to classify the image or get backbone PCA features (default: %d)\n", (int)params.classify);
+    fprintf(stderr, "  -fa, --flash_attn          whether to enable flash_attn, less accurate (default: %d)\n\n", (int)params.enable_flash_attn);
+}
+
+// dinov2.h:116 / dinov2.cpp:865-898.  One deliberate difference: -o sets image_out (the reference overwrites fname_inp, :875).
+inline bool dino_params_parse(int argc, char** argv, dino_params& params) {
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
+        if (a == "-s" || a == "--seed") params.seed = (uint32_t)atoi(next());
+        else if (a == "-m" || a == "--model") params.model = next();
+        else if (a == "-i" || a == "--inp") params.fname_inp = next();
+        else if (a == "-o" || a == "--out") params.image_out = next();
+        else if (a == "-t" || a == "--threads") params.n_threads = (uint32_t)atoi(next());
+        else if (a == "-k" || a == "--topk") params.topk = (uint32_t)atoi(next());
+        else if (a == "-cid" || a == "--camera_id") params.camera_id = (uint8_t)atoi(next());
+        else if (a == "-fa" || a == "--flash_attn") params.enable_flash_attn = true;
+        else if (a == "-c" || a == "--classify") params.classify = true;
+        else {
+            if (a != "-h" && a != "--help") fprintf(stderr, "error: unknown argument: %s\n", a.c_str());
+            print_usage(argc, argv, params);
+            exit(0);
+        }
+    }
+    return true;
 }
 
 // dinov2.h:118 / dinov2.cpp:355-453
