@@ -21,3 +21,19 @@ for name, fn in (("host f32 RGB_CHW", lambda: sess.predict(f32, classify=True, w
     for _ in range(5): fn()
     dt = (time.perf_counter() - t0) / 5
     print(f"{name}: {B / dt:.1f} images/s ({dt * 1e3:.1f} ms per batch of {B})")
+
+# two sessions on two host threads: one's host -> device copy runs under the other's forward
+import threading
+model = sess.model
+pair = [api.Session(model), api.Session(model)]
+for sx in pair:
+    sx.predict(f32, classify=True, want=("logits",))
+def _worker(sx):
+    for _ in range(5):
+        sx.predict(f32, classify=True, want=("logits",))
+ts = [threading.Thread(target=_worker, args=(sx,)) for sx in pair]
+t0 = time.perf_counter()
+for t in ts: t.start()
+for t in ts: t.join()
+dt = time.perf_counter() - t0
+print(f"host f32, two sessions on two threads: {2 * 5 * B / dt:.1f} images/s")
