@@ -76,6 +76,9 @@ hipError_t launch_head(DType dt, const float* fin, const void* W, const float* b
                        float* logits, float* probs, int B, int T, int H, int C, int first, float inv_div,
                        hipStream_t stream);
 
+// PCA support: mean[h] = column mean of tok [P, H]; xt [H, Ppad] f16 = (tok - mean)^T, zero padded in P
+hipError_t launch_pca_prepare(const float* tok, float* mean, void* xt, int P, int H, int Ppad, hipStream_t stream);
+
 // debugging aid: what ds_read_b64_tr_b16 returns per lane for addr = lane*8 over an LDS image holding its own
 // element index (out: [64][4] int16)
 hipError_t launch_probe_tr16(int16_t* out, hipStream_t stream);

@@ -442,4 +442,52 @@ hipError_t launch_head(DType dt, const float* fin, const void* W, const float* b
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// PCA support (cv::PCA of inference.cpp:76-81): column means of a token matrix and its centred,
+// transposed f16 copy Xt[H][Ppad] (zero padded in P), so that the covariance P * C = Xt Xt^T is one plain GEMM on the matrix
+// cores (A = W = Xt).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void pca_mean_kernel(const float* __restrict__ tok, float* __restrict__ mean, int P, int H) {
+    constexpr int G = 16;
+    __shared__ double part[G][64];
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (h < H)
+        for (int t = g; t < P; t += G) s += (double)tok[(size_t)t * H + h];
+    part[g][lane] = s;
+    __syncthreads();
+    if (g == 0 && h < H) {
+        double tot = 0.0;
+#pragma unroll
+        for (int i = 0; i < G; ++i) tot += part[i][lane];
+        mean[h] = (float)(tot / P);
+    }
+}
+
+__global__ __launch_bounds__(256) void pca_center_transpose_kernel(const float* __restrict__ tok, const float* __restrict__ mean,
+                                                                   _Float16* __restrict__ xt, int P, int H, int Ppad) {
+    __shared__ float tile[32][33];
+    const int p0 = blockIdx.x * 32, h0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = p0 + ty + 8 * i, h = h0 + tx;
+        tile[ty + 8 * i][tx] = (p < P && h < H) ? tok[(size_t)p * H + h] - mean[h] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = h0 + ty + 8 * i, p = p0 + tx;
+        if (h < H && p < Ppad) xt[(size_t)h * Ppad + p] = (_Float16)tile[tx][ty + 8 * i];
+    }
+}
+
+hipError_t launch_pca_prepare(const float* tok, float* mean, void* xt, int P, int H, int Ppad, hipStream_t st) {
+    hipLaunchKernelGGL(pca_mean_kernel, dim3((H + 63) / 64), dim3(1024), 0, st, tok, mean, P, H);
+    hipLaunchKernelGGL(pca_center_transpose_kernel, dim3((Ppad + 31) / 32, (H + 31) / 32), dim3(256), 0, st, tok, mean,
+                       (_Float16*)xt, P, H, Ppad);
+    return hipGetLastError();
+}
+
 }  // namespace dinov2

@@ -938,3 +938,166 @@ extern "C" int dinov2_hip_debug_hidden(dinov2_hip_session* s, const dinov2_hip_i
     HIP_TRY(hipStreamSynchronize(s->stream));
     return DINOV2_HIP_OK;
 }
+
+namespace dinov2 {
+// comp [3, H] = the three leading unit eigenvectors of the symmetric matrix cov [H, H] (H >= 4), by variance, each with its
+// largest loading positive.  Host code; also reachable through dinov2_hip_op_eig3 for the CPU tests.
+void top3_eigenvectors(const float* cov_p, int H, double* comp) {
+    const float* cov = cov_p;
+    // three leading eigenvectors of the symmetric H x H matrix: subspace iteration with a block of NB >= 3 vectors (the
+    // wanted three then converge like (lambda_{NB+1} / lambda_3)^k) and a Rayleigh-Ritz step per iteration, all in double
+    const int NB = std::min(8, H);
+    constexpr int LD = 8;  // row stride of Q / Y: fixed so that the inner loops below vectorise; columns >= NB stay zero
+    std::vector<double> Q((size_t)H * LD, 0.0), Y((size_t)H * LD, 0.0), Bm((size_t)NB * NB), V((size_t)NB * NB);
+    for (int j = 0; j < H; ++j)
+        for (int c = 0; c < NB; ++c) Q[(size_t)j * LD + c] = std::sin(0.37 * (j + 1) * (c + 1)) + (c == j % NB ? 0.5 : 0.0);
+    auto orthonormalise = [&](std::vector<double>& M) {  // modified Gram-Schmidt, twice for safety
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c = 0; c < NB; ++c) {
+                for (int k = 0; k < c; ++k) {
+                    double d = 0;
+                    for (int j = 0; j < H; ++j) d += M[(size_t)j * LD + k] * M[(size_t)j * LD + c];
+                    for (int j = 0; j < H; ++j) M[(size_t)j * LD + c] -= d * M[(size_t)j * LD + k];
+                }
+                double n = 0;
+                for (int j = 0; j < H; ++j) n += M[(size_t)j * LD + c] * M[(size_t)j * LD + c];
+                n = std::sqrt(n);
+                if (n > 0)
+                    for (int j = 0; j < H; ++j) M[(size_t)j * LD + c] /= n;
+            }
+    };
+    auto multiply = [&]() {  // Y = C Q, Bm = Q^T Y
+        std::fill(Bm.begin(), Bm.end(), 0.0);
+        for (int i = 0; i < H; ++i) {
+            double y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* row = cov + (size_t)i * H;
+            for (int j = 0; j < H; ++j) {
+                const double cij = row[j];
+                for (int c = 0; c < LD; ++c) y[c] += cij * Q[(size_t)j * LD + c];
+            }
+            for (int c = 0; c < LD; ++c) Y[(size_t)i * LD + c] = y[c];
+            for (int r = 0; r < NB; ++r)
+                for (int c = 0; c < NB; ++c) Bm[(size_t)r * NB + c] += Q[(size_t)i * LD + r] * y[c];
+        }
+    };
+    int order[8];
+    auto ritz = [&]() {  // cyclic Jacobi on the NB x NB matrix Bm: eigenvalues on its diagonal, eigenvectors in V's columns
+        std::fill(V.begin(), V.end(), 0.0);
+        for (int k = 0; k < NB; ++k) V[(size_t)k * NB + k] = 1.0;
+        for (int r = 0; r < NB; ++r)
+            for (int c = r + 1; c < NB; ++c) Bm[(size_t)r * NB + c] = Bm[(size_t)c * NB + r] = 0.5 * (Bm[(size_t)r * NB + c] + Bm[(size_t)c * NB + r]);
+        for (int sweep = 0; sweep < 40; ++sweep) {
+            double off = 0, diag = 0;
+            for (int r = 0; r < NB; ++r)
+                for (int c = 0; c < NB; ++c) (r == c ? diag : off) += Bm[(size_t)r * NB + c] * Bm[(size_t)r * NB + c];
+            if (off <= 1e-30 * diag) break;
+            for (int pp = 0; pp < NB - 1; ++pp)
+                for (int q = pp + 1; q < NB; ++q) {
+                    const double apq = Bm[(size_t)pp * NB + q];
+                    if (apq == 0.0) continue;
+                    const double th = 0.5 * std::atan2(2 * apq, Bm[(size_t)q * NB + q] - Bm[(size_t)pp * NB + pp]);
+                    const double c = std::cos(th), sn = std::sin(th);
+                    for (int k = 0; k < NB; ++k) {
+                        const double x = Bm[(size_t)k * NB + pp], y = Bm[(size_t)k * NB + q];
+                        Bm[(size_t)k * NB + pp] = c * x - sn * y; Bm[(size_t)k * NB + q] = sn * x + c * y;
+                    }
+                    for (int k = 0; k < NB; ++k) {
+                        const double x = Bm[(size_t)pp * NB + k], y = Bm[(size_t)q * NB + k];
+                        Bm[(size_t)pp * NB + k] = c * x - sn * y; Bm[(size_t)q * NB + k] = sn * x + c * y;
+                    }
+                    for (int k = 0; k < NB; ++k) {
+                        const double x = V[(size_t)k * NB + pp], y = V[(size_t)k * NB + q];
+                        V[(size_t)k * NB + pp] = c * x - sn * y; V[(size_t)k * NB + q] = sn * x + c * y;
+                    }
+                }
+        }
+        for (int k = 0; k < NB; ++k) order[k] = k;
+        std::sort(order, order + NB, [&](int x, int y) { return Bm[(size_t)x * NB + x] > Bm[(size_t)y * NB + y]; });
+    };
+    orthonormalise(Q);
+    double prev[3] = {0, 0, 0};
+    for (int it = 0; it < 300; ++it) {
+        multiply();
+        ritz();
+        bool done = it > 2;
+        for (int c = 0; c < 3; ++c) {
+            const double ev = Bm[(size_t)order[c] * NB + order[c]];
+            if (std::fabs(ev - prev[c]) > 1e-9 * std::fabs(Bm[(size_t)order[0] * NB + order[0]])) done = false;
+            prev[c] = ev;
+        }
+        if (done) break;  // Q (not yet advanced) with this V is the converged Ritz basis
+        Q.swap(Y);
+        orthonormalise(Q);
+    }
+    for (int c = 0; c < 3; ++c) {
+        const int o = order[c];
+        int big = 0;
+        double nrm = 0;
+        for (int j = 0; j < H; ++j) {
+            double v = 0;
+            for (int k = 0; k < NB; ++k) v += Q[(size_t)j * LD + k] * V[(size_t)k * NB + o];
+            comp[(size_t)c * H + j] = v;
+            nrm += v * v;
+            if (std::fabs(v) > std::fabs(comp[(size_t)c * H + big])) big = j;
+        }
+        const double sc = (comp[(size_t)c * H + big] < 0 ? -1.0 : 1.0) / std::sqrt(nrm);  // unit length, largest loading positive
+        for (int j = 0; j < H; ++j) comp[(size_t)c * H + j] *= sc;
+    }
+}
+}  // namespace dinov2
+
+// =============================================================================================================
+// PCA of patch tokens (cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project, inference.cpp:76-81)
+// =============================================================================================================
+extern "C" int dinov2_hip_pca3(dinov2_hip_session* s, const float* tokens, int32_t P, int32_t H, int32_t on_device,
+                               float* components, float* mean, float* projection, char* err, size_t errlen) {
+    if (!s || !tokens || P < 4 || H < 4 || H > 4096) {
+        set_err(err, errlen, "pca3: need tokens [P >= 4, 4 <= H <= 4096]");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    HIP_TRY(hipSetDevice(s->model->device));
+    hipStream_t st = s->stream;
+    const int Ppad = (P + 127) / 128 * 128;  // K of the covariance GEMM: multiple of 64 with an even K / 64
+    const size_t n_tok = (size_t)P * H * 4, n_xt = (size_t)H * Ppad * 2, n_cov = (size_t)H * H * 4, n_mean = (size_t)H * 4;
+    const size_t need = align_up(n_tok, 256) + align_up(n_xt, 256) + align_up(n_cov, 256) + align_up(n_mean, 256);
+    char* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, need));
+    struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{buf};
+    float* d_tok = (float*)buf;
+    char* d_xt = buf + align_up(n_tok, 256);
+    float* d_cov = (float*)(d_xt + align_up(n_xt, 256));
+    float* d_mean = (float*)((char*)d_cov + align_up(n_cov, 256));
+    const float* tok = tokens;
+    if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(d_tok, tokens, n_tok, hipMemcpyHostToDevice, st));
+        tok = d_tok;
+    }
+    HIP_TRY(launch_pca_prepare(tok, d_mean, d_xt, P, H, Ppad, st));
+    GemmArgs a{};  // P * C = Xt Xt^T: both operands are the same [H, Ppad] matrix
+    a.A = d_xt; a.W = d_xt; a.out = d_cov; a.M = H; a.N = H; a.K = Ppad; a.ldo = H;
+    HIP_TRY(launch_gemm(DT_F16, EPI_PLAIN_F32, a, st));
+    std::vector<float> cov((size_t)H * H), mu((size_t)H), host_tok;
+    HIP_TRY(hipMemcpyAsync(cov.data(), d_cov, n_cov, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(mu.data(), d_mean, n_mean, hipMemcpyDeviceToHost, st));
+    if (on_device && projection) {
+        host_tok.resize((size_t)P * H);
+        HIP_TRY(hipMemcpyAsync(host_tok.data(), tokens, n_tok, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+
+    std::vector<double> comp((size_t)3 * H);
+    dinov2::top3_eigenvectors(cov.data(), H, comp.data());
+    if (components)
+        for (size_t i = 0; i < comp.size(); ++i) components[i] = (float)comp[i];
+    if (mean) std::memcpy(mean, mu.data(), n_mean);
+    if (projection) {
+        const float* t = on_device ? host_tok.data() : tokens;
+        for (int p = 0; p < P; ++p)
+            for (int c = 0; c < 3; ++c) {
+                double d = 0;
+                for (int j = 0; j < H; ++j) d += ((double)t[(size_t)p * H + j] - mu[(size_t)j]) * comp[(size_t)c * H + j];
+                projection[(size_t)p * 3 + c] = (float)d;
+            }
+    }
+    return DINOV2_HIP_OK;
+}

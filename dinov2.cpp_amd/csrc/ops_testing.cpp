@@ -9,6 +9,7 @@
 #include <cstring>
 #include <vector>
 
+#include "../../include/dinov2_hip.h"
 #include "../../include/dinov2_hip_ops.h"
 #include "kernels.h"
 
@@ -254,4 +255,12 @@ extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return ms / iters;
+}
+
+namespace dinov2 { void top3_eigenvectors(const float* cov, int H, double* comp); }
+// host-only: the eigen-solve behind dinov2_hip_pca3, for the CPU test-suite
+extern "C" int dinov2_hip_op_eig3(const float* cov, int32_t H, double* comp) {
+    if (!cov || !comp || H < 4) return DINOV2_HIP_ERR_INVALID;
+    dinov2::top3_eigenvectors(cov, H, comp);
+    return 0;
 }

@@ -18,10 +18,14 @@ import numpy as np
 from . import api
 
 
-def pca_visual(patch_tokens: np.ndarray, rows: int, cols: int, out_h: int, out_w: int) -> np.ndarray:
+def pca_visual(patch_tokens: np.ndarray, rows: int, cols: int, out_h: int, out_w: int, session=None) -> np.ndarray:
     """cv::PCA(DATA_AS_ROW, 3) + project + normalize(0, 255, NORM_MINMAX, CV_8U) + reshape + resize(INTER_NEAREST)
     (inference.cpp:76-92).  Returns uint8 [out_h, out_w, 3].  Eigenvector signs are a free choice in any PCA; here each
-    component is oriented so that its largest-magnitude loading is positive."""
+    component is oriented so that its largest-magnitude loading is positive.  With a `session` the means and the covariance
+    are computed on the device (dinov2_hip_pca3); without one this is the host tool's numpy path."""
+    if session is not None:
+        _, _, proj = session.pca3(patch_tokens)
+        return _render(proj, rows, cols, out_h, out_w)
     try:  # a 2 170 x 1 024 problem spread over hundreds of BLAS threads is slower than over eight
         from threadpoolctl import threadpool_limits
         with threadpool_limits(limits=8):
@@ -50,6 +54,10 @@ def _pca_visual(patch_tokens, rows, cols, out_h, out_w):
         if c[np.abs(c).argmax()] < 0:
             c *= -1
     proj = xc @ comp.T.astype(np.float32)                        # [P, 3]; same dtype on both sides keeps this a BLAS call
+    return _render(proj, rows, cols, out_h, out_w)
+
+
+def _render(proj, rows, cols, out_h, out_w):
     lo, hi = float(proj.min()), float(proj.max())
     norm = np.zeros_like(proj) if hi == lo else (proj - lo) * (255.0 / (hi - lo))
     img = np.rint(norm).clip(0, 255).astype(np.uint8).reshape(rows, cols, 3)
@@ -139,7 +147,7 @@ def main(argv=None) -> int:
                 print(f" > {model.id2label.get(int(i), str(int(i)))} : {pr:.2f}")
         return 0
     rows, cols = oh // hp.patch_size, ow // hp.patch_size
-    vis = pca_visual(r["patch_tokens"][0], rows, cols, oh, ow)
+    vis = pca_visual(r["patch_tokens"][0], rows, cols, oh, ow, session=sess)
     try:
         Image.fromarray(np.ascontiguousarray(vis[:, :, ::-1])).save(p.image_out)  # stored BGR like the cv::Mat -> RGB file
         print(f"main: Saved image to: {p.image_out}", file=sys.stderr)

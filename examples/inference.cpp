@@ -58,60 +58,6 @@ bool write_ppm_from_bgr(const std::string& path, const std::vector<uint8_t>& bgr
     return ok;
 }
 
-// cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project (inference.cpp:76-81): the three leading eigenvectors of the H x H
-// covariance by power iteration with deflation, on the P x P Gram matrix when P < H.  Component signs: largest loading > 0.
-void pca3_project(const float* x, int P, int H, std::vector<float>& proj) {
-    std::vector<double> mean((size_t)H, 0.0);
-    for (int p = 0; p < P; ++p)
-        for (int j = 0; j < H; ++j) mean[(size_t)j] += x[(size_t)p * H + j];
-    for (auto& m : mean) m /= P;
-    std::vector<double> xc((size_t)P * H);
-    for (int p = 0; p < P; ++p)
-        for (int j = 0; j < H; ++j) xc[(size_t)p * H + j] = x[(size_t)p * H + j] - mean[(size_t)j];
-    std::vector<std::vector<double>> comps;
-    for (int c = 0; c < 3; ++c) {
-        std::vector<double> v((size_t)H), t((size_t)P);
-        for (int j = 0; j < H; ++j) v[(size_t)j] = std::sin(0.37 * (j + 1) * (c + 1)) + 0.01;  // fixed start: deterministic
-        std::vector<double> prev((size_t)H, 0.0);
-        for (int it = 0; it < 300; ++it) {
-            for (const auto& u : comps) {  // deflate: stay orthogonal to the components already found
-                double d = 0;
-                for (int j = 0; j < H; ++j) d += u[(size_t)j] * v[(size_t)j];
-                for (int j = 0; j < H; ++j) v[(size_t)j] -= d * u[(size_t)j];
-            }
-            for (int p = 0; p < P; ++p) {  // t = Xc v ; v = Xc^T t  (one step of power iteration on Xc^T Xc)
-                double d = 0;
-                for (int j = 0; j < H; ++j) d += xc[(size_t)p * H + j] * v[(size_t)j];
-                t[(size_t)p] = d;
-            }
-            std::fill(v.begin(), v.end(), 0.0);
-            for (int p = 0; p < P; ++p)
-                for (int j = 0; j < H; ++j) v[(size_t)j] += xc[(size_t)p * H + j] * t[(size_t)p];
-            double n = 0;
-            for (double a : v) n += a * a;
-            n = std::sqrt(n);
-            if (n == 0) break;
-            for (auto& a : v) a /= n;
-            double dot = 0;
-            for (int j = 0; j < H; ++j) dot += v[(size_t)j] * prev[(size_t)j];
-            if (std::fabs(dot) > 1.0 - 1e-12) break;  // converged
-            prev = v;
-        }
-        int big = 0;
-        for (int j = 1; j < H; ++j)
-            if (std::fabs(v[(size_t)j]) > std::fabs(v[(size_t)big])) big = j;
-        if (v[(size_t)big] < 0) for (auto& a : v) a = -a;
-        comps.push_back(v);
-    }
-    proj.assign((size_t)P * 3, 0.f);
-    for (int p = 0; p < P; ++p)
-        for (int c = 0; c < 3; ++c) {
-            double d = 0;
-            for (int j = 0; j < H; ++j) d += xc[(size_t)p * H + j] * comps[(size_t)c][(size_t)j];
-            proj[(size_t)p * 3 + c] = (float)d;
-        }
-}
-
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -150,8 +96,14 @@ int main(int argc, char** argv) {
     if (!output) return 1;
     if (output->patch_tokens) {
         const Mat32f& tok = *output->patch_tokens;
-        std::vector<float> proj;
-        pca3_project(tok.data, tok.rows, tok.cols, proj);
+        // cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project (inference.cpp:76-81): covariance on the device, see dinov2_hip.h
+        std::vector<float> proj((size_t)tok.rows * 3);
+        char err[256] = {0};
+        if (dinov2_hip_pca3(model.default_session, tok.data, tok.rows, tok.cols, 0, nullptr, nullptr, proj.data(), err, sizeof err) !=
+            DINOV2_HIP_OK) {
+            fprintf(stderr, "%s: PCA failed: %s\n", __func__, err);
+            return 1;
+        }
         float lo = proj[0], hi = proj[0];
         for (float v : proj) { lo = std::min(lo, v); hi = std::max(hi, v); }
         const int gr = oh / ps, gc = ow / ps;

@@ -133,6 +133,14 @@ int dinov2_hip_predict(dinov2_hip_session *session, const dinov2_hip_input *in, 
 int dinov2_hip_preprocess_size(int32_t mode, int32_t height, int32_t width, int32_t patch, int32_t *out_h, int32_t *out_w);
 int dinov2_hip_preprocess(int32_t mode, const uint8_t *bgr, int32_t height, int32_t width, int32_t patch, float *out);
 
+/* -- feature post-processing (replaces cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project of
+ *    inference.cpp:76-81).  tokens: [P, H] f32, host or device.  Column means and the H x H covariance are computed on the
+ *    device (the covariance as one MFMA GEMM of the centred, transposed f16 tokens with themselves); the three leading
+ *    eigenvectors by subspace iteration on the host.  Outputs (host, any may be NULL): components [3, H] unit vectors sorted by
+ *    variance, each oriented so that its largest loading is positive; mean [H]; projection [P, 3] = (tokens - mean) components^T. */
+int dinov2_hip_pca3(dinov2_hip_session *session, const float *tokens, int32_t P, int32_t H, int32_t on_device,
+                    float *components, float *mean, float *projection, char *err, size_t errlen);
+
 /* -- quantise a GGUF (replaces dino_model_quantize, dinov2.h:118 / dinov2.cpp:355-453).  Host only.
  *    itype: ggml type id 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0.  2-D tensors named `*weight` are re-encoded, the rest copied. */
 int dinov2_hip_quantize(const char *fname_inp, const char *fname_out, int32_t itype, char *err, size_t errlen);

@@ -293,3 +293,23 @@ def test_native_quantize_equals_python_tool(api, pkg, golden_dir, tmp_path, ityp
     err = C.create_string_buffer(256)
     assert api.lib().dinov2_hip_quantize(srcs[0].encode(), str(tmp_path / "x.gguf").encode(), 5, err, 256) == 4  # invalid type
     assert api.lib().dinov2_hip_quantize(b"/nonexistent.gguf", str(tmp_path / "x.gguf").encode(), 8, err, 256) == 1
+
+
+@pytest.mark.parametrize("H,decay", [(4, 0.5), (7, 0.6), (32, 0.7), (384, 0.9), (1024, 0.95)])
+def test_pca_eigen_solve_matches_eigh(pkg, H, decay):
+    """The host half of dinov2_hip_pca3 (block subspace iteration + Rayleigh-Ritz, csrc/model.cpp top3_eigenvectors) against
+    numpy's eigh on symmetric matrices with a geometric spectrum: same three leading eigenvectors, unit length, sign convention
+    'largest loading positive'.  No device call."""
+    api = import_module(pkg.__name__ + ".api")
+    rng = np.random.default_rng(H)
+    q = np.linalg.qr(rng.standard_normal((H, H)))[0]
+    cov = ((q * (100.0 * decay ** np.arange(H))) @ q.T).astype(np.float32)
+    comp = np.empty((3, H), np.float64)
+    assert api.lib().dinov2_hip_op_eig3(cov.ctypes.data, H, comp.ctypes.data) == 0
+    _, v = np.linalg.eigh(cov.astype(np.float64))
+    ref = v[:, ::-1][:, :3].T
+    np.testing.assert_allclose(np.linalg.norm(comp, axis=1), 1.0, atol=1e-12)
+    for k in range(3):
+        assert abs(float(comp[k] @ ref[k])) >= 1 - 1e-7
+        assert comp[k][np.abs(comp[k]).argmax()] > 0
+    assert api.lib().dinov2_hip_op_eig3(cov.ctypes.data, 3, comp.ctypes.data) != 0

@@ -344,3 +344,33 @@ def test_random_shapes_vs_oracle(api, golden_dir, name):
         assert _rel(got["patch_tokens"][b], exp["patch_tokens"]) <= 5e-3, (B, h, w, classify)
         if classify:
             assert _rel(got["logits"][b], exp["logits"]) <= 1e-3, (B, h, w)
+
+
+@pytest.mark.parametrize("P,H", [(256, 384), (1369, 1024), (2170, 1536), (37, 32), (700, 100)])
+def test_pca3_matches_svd(api, golden_dir, P, H):
+    """dinov2_hip_pca3 (device means + covariance on the matrix cores, host subspace iteration) against numpy's SVD of the
+    centred tokens -- the PCA of inference.cpp:76-81.  Tokens get a clear three-direction structure on top of noise, as patch
+    tokens have.  Tolerances: |cos| between matching components >= 0.999 (the covariance is accumulated from f16-rounded
+    centred tokens), projections within 1% of the largest projection."""
+    sess = api.Session(api.Model(os.path.join(golden_dir, "tiny_gelu_reg4.gguf"), classify=False))
+    rng = np.random.default_rng(P * 7 + H)
+    basis = np.linalg.qr(rng.standard_normal((H, 3)))[0].T                                  # [3, H] orthonormal
+    x = (rng.standard_normal((P, 3)) * np.array([9.0, 5.0, 2.5])) @ basis + 0.3 * rng.standard_normal((P, H)) + 4.0
+    x = x.astype(np.float32)
+    comp, mean, proj = sess.pca3(x)
+    xc = x.astype(np.float64) - x.mean(0, dtype=np.float64)
+    _, _, vt = np.linalg.svd(xc, full_matrices=False)
+    ref = vt[:3]
+    for c in ref:
+        if c[np.abs(c).argmax()] < 0:
+            c *= -1
+    np.testing.assert_allclose(mean, x.mean(0, dtype=np.float64), atol=1e-5)
+    np.testing.assert_allclose(np.linalg.norm(comp, axis=1), 1.0, atol=1e-5)
+    for k in range(3):
+        assert abs(float(comp[k].astype(np.float64) @ ref[k])) >= 0.999, k
+        assert comp[k][np.abs(comp[k]).argmax()] > 0
+    want = xc @ comp.astype(np.float64).T                                                     # projection is self-consistent
+    assert np.abs(proj - want).max() <= 1e-3 * max(1.0, np.abs(want).max())
+    assert np.abs(np.abs(proj) - np.abs(xc @ ref.T)).max() <= 1e-2 * np.abs(xc @ ref.T).max()
+    with pytest.raises(api.DinoError):
+        sess.pca3(np.zeros((2, 8), np.float32))

@@ -114,3 +114,31 @@ def test_cpp_inference_end_to_end(golden_dir, tmp_path):
     assert r.returncode == 0 and "Saved image to" in r.stderr and "preprocessed image (70 x 84)" in r.stderr, r.stderr
     hdr = open(out, "rb").read(15)
     assert hdr.startswith(b"P6\n84 70\n255\n")
+    # the Python CLI renders the same map (both go through dinov2_hip_pca3): identical pixels
+    pyout = str(tmp_path / "pca_py.png")
+    py = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, '.'); from __graft_entry__ import load_package, PKG_NAME; "
+                         "load_package(); from importlib import import_module; "
+                         f"sys.exit(import_module(PKG_NAME + '.inference').main(['inference', '-m', r'{gguf}', '-i', r'{png}', '-o', r'{pyout}']))"],
+                        capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert py.returncode == 0, py.stderr
+    cpp_img = np.frombuffer(open(out, "rb").read()[len(b"P6\n84 70\n255\n"):], np.uint8).reshape(70, 84, 3)
+    assert np.array_equal(np.asarray(Image.open(pyout).convert("RGB")), cpp_img)
+
+
+@pytest.mark.gpu
+def test_pca_visual_device_matches_host(golden_dir):
+    """pca_visual with a session (device covariance) against the numpy path on structured tokens: same picture up to one grey
+    level (the covariance is accumulated from f16-rounded centred tokens)."""
+    from __graft_entry__ import load_package, PKG_NAME
+    load_package()
+    from importlib import import_module
+    api, inf = import_module(PKG_NAME + ".api"), import_module(PKG_NAME + ".inference")
+    sess = api.Session(api.Model(os.path.join(golden_dir, "tiny_gelu_reg4.gguf"), classify=False))
+    rng = np.random.default_rng(5)
+    rows, cols, H = 16, 20, 384
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    lat = np.stack([np.sin(yy / 3.0), np.cos(xx / 4.0), (yy + xx) / 20.0], -1).reshape(-1, 3) * np.array([8.0, 5.0, 3.0])
+    tok = (lat @ np.linalg.qr(rng.standard_normal((H, 3)))[0].T + 0.05 * rng.standard_normal((rows * cols, H))).astype(np.float32)
+    a = inf.pca_visual(tok, rows, cols, rows * 14, cols * 14, session=sess).astype(np.int32)
+    b = inf.pca_visual(tok, rows, cols, rows * 14, cols * 14).astype(np.int32)
+    assert a.shape == (rows * 14, cols * 14, 3) and np.abs(a - b).max() <= 1
