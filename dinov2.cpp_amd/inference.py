@@ -58,11 +58,13 @@ def _pca_visual(patch_tokens, rows, cols, out_h, out_w):
 
 
 def _render(proj, rows, cols, out_h, out_w):
-    lo, hi = float(proj.min()), float(proj.max())
-    norm = np.zeros_like(proj) if hi == lo else (proj - lo) * (255.0 / (hi - lo))
+    proj = np.asarray(proj, np.float32)
+    lo, hi = proj.min(), proj.max()                                     # all in f32, like the C++ program
+    norm = np.zeros_like(proj) if hi == lo else (proj - lo) * (np.float32(255.0) / (hi - lo))
     img = np.rint(norm).clip(0, 255).astype(np.uint8).reshape(rows, cols, 3)
-    yy = np.minimum((np.arange(out_h) * (rows / out_h)).astype(np.int64), rows - 1)   # INTER_NEAREST: floor(dst * scale)
-    xx = np.minimum((np.arange(out_w) * (cols / out_w)).astype(np.int64), cols - 1)
+    # cv::resize(INTER_NEAREST): source index = min(floor(dst * ifx), src - 1) with ifx = 1 / (dst_size / src_size)
+    yy = np.minimum(np.floor(np.arange(out_h) * (1.0 / (out_h / rows))).astype(np.int64), rows - 1)
+    xx = np.minimum(np.floor(np.arange(out_w) * (1.0 / (out_w / cols))).astype(np.int64), cols - 1)
     return img[yy][:, xx]
 
 

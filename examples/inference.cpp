@@ -111,10 +111,12 @@ int main(int argc, char** argv) {
         for (size_t i = 0; i < small.size(); ++i)
             small[i] = (uint8_t)std::min(255.0f, std::max(0.0f, std::nearbyint(hi == lo ? 0.f : (proj[i] - lo) * (255.0f / (hi - lo)))));
         std::vector<uint8_t> big((size_t)oh * ow * 3);
-        for (int y = 0; y < oh; ++y) {  // cv::resize(INTER_NEAREST): source index = floor(dst * scale)
-            const int sy = std::min((int)((double)y * gr / oh), gr - 1);
+        // cv::resize(INTER_NEAREST): source index = min(floor(dst * ifx), src - 1) with ifx = 1 / (dst_size / src_size)
+        const double ify = 1.0 / ((double)oh / gr), ifx = 1.0 / ((double)ow / gc);
+        for (int y = 0; y < oh; ++y) {
+            const int sy = std::min((int)std::floor(y * ify), gr - 1);
             for (int x = 0; x < ow; ++x) {
-                const int sx = std::min((int)((double)x * gc / ow), gc - 1);
+                const int sx = std::min((int)std::floor(x * ifx), gc - 1);
                 memcpy(&big[((size_t)y * ow + x) * 3], &small[((size_t)sy * gc + sx) * 3], 3);
             }
         }

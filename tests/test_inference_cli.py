@@ -114,7 +114,8 @@ def test_cpp_inference_end_to_end(golden_dir, tmp_path):
     assert r.returncode == 0 and "Saved image to" in r.stderr and "preprocessed image (70 x 84)" in r.stderr, r.stderr
     hdr = open(out, "rb").read(15)
     assert hdr.startswith(b"P6\n84 70\n255\n")
-    # the Python CLI renders the same map (both go through dinov2_hip_pca3): identical pixels
+    # the Python CLI renders the same map (both go through dinov2_hip_pca3).  The two programs hand the image over differently
+    # (u8 BGR to the device-side preprocessing vs the shim's host preprocessing to f32), so allow one grey level on a few cells
     pyout = str(tmp_path / "pca_py.png")
     py = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, '.'); from __graft_entry__ import load_package, PKG_NAME; "
                          "load_package(); from importlib import import_module; "
@@ -122,7 +123,9 @@ def test_cpp_inference_end_to_end(golden_dir, tmp_path):
                         capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert py.returncode == 0, py.stderr
     cpp_img = np.frombuffer(open(out, "rb").read()[len(b"P6\n84 70\n255\n"):], np.uint8).reshape(70, 84, 3)
-    assert np.array_equal(np.asarray(Image.open(pyout).convert("RGB")), cpp_img)
+    py_img = np.asarray(Image.open(pyout).convert("RGB"))
+    d = np.abs(py_img.astype(np.int32) - cpp_img.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() <= 0.05, (int(d.max()), int((d > 0).sum()), np.argwhere(d > 0)[:8].tolist())
 
 
 @pytest.mark.gpu
