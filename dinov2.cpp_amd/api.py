@@ -116,7 +116,7 @@ def lib():
     L.dinov2_hip_op_attention.argtypes = [i32, fp, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_layernorm.argtypes = [i32, fp, fp, fp, fp, i32, i32, C.c_float]
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
-    L.dinov2_hip_op_eig3.argtypes = [vp, i32, vp]
+    L.dinov2_hip_op_pca_ritz.argtypes = [vp, vp, vp, i32, vp, vp]
     L.dinov2_hip_op_probe_tr16.argtypes = [C.POINTER(C.c_int16)]
     L.dinov2_hip_op_gemm_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_gemm_bench.restype = C.c_float
@@ -294,17 +294,23 @@ class Session:
             raise DinoError(rc, err.value.decode(errors="replace"))
         return out
 
-    def pca3(self, tokens: np.ndarray) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
-        """Top-3 PCA of a [P, H] token matrix (cv::PCA(DATA_AS_ROW, 3) + project, inference.cpp:76-81): means and covariance on
-        the device, eigenvectors on the host.  Returns (components [3, H], mean [H], projection [P, 3])."""
-        x = np.ascontiguousarray(tokens, dtype=np.float32)
-        if x.ndim != 2:
-            raise ValueError("pca3: tokens must be [P, H]")
-        P, H = x.shape
+    def pca3(self, tokens: np.ndarray | None = None, shape: tuple[int, int] | None = None):
+        """Top-3 PCA of a [P, H] token matrix (cv::PCA(DATA_AS_ROW, 3) + project, inference.cpp:76-81), on the device: means,
+        covariance (one MFMA GEMM), block iteration for the eigenvectors, projection.  `tokens=None` works on the patch tokens
+        the last predict() left on the device (image 0; `shape` = their (P, H)) without moving them.
+        Returns (components [3, H], mean [H], projection [P, 3])."""
+        if tokens is None:
+            P, H = shape
+            ptr = None
+        else:
+            x = np.ascontiguousarray(tokens, dtype=np.float32)
+            if x.ndim != 2:
+                raise ValueError("pca3: tokens must be [P, H]")
+            P, H = x.shape
+            ptr = x.ctypes.data
         comp, mean, proj = np.empty((3, H), np.float32), np.empty(H, np.float32), np.empty((P, 3), np.float32)
         err = _errbuf()
-        rc = lib().dinov2_hip_pca3(self._h, x.ctypes.data, P, H, 0, comp.ctypes.data, mean.ctypes.data, proj.ctypes.data,
-                                   err, len(err))
+        rc = lib().dinov2_hip_pca3(self._h, ptr, P, H, 0, comp.ctypes.data, mean.ctypes.data, proj.ctypes.data, err, len(err))
         if rc != 0:
             raise DinoError(rc, err.value.decode(errors="replace"))
         return comp, mean, proj

@@ -79,6 +79,49 @@ hipError_t launch_head(DType dt, const float* fin, const void* W, const float* b
 // PCA support: mean[h] = column mean of tok [P, H]; xt [H, Ppad] f16 = (tok - mean)^T, zero padded in P
 hipError_t launch_pca_prepare(const float* tok, float* mean, void* xt, int P, int H, int Ppad, hipStream_t stream);
 
+// Block iteration for the leading eigenvectors of cov [H, H] (see pca_power_kernel): block width, rows per workgroup, grid size
+constexpr int PCA_NB = 8, PCA_ROWS = 16;
+inline int pca_blocks(int H) { return (H + PCA_ROWS - 1) / PCA_ROWS; }
+// g [8][8] = Y^T Y  ->  rinv [8][8] upper triangular with Y rinv orthonormal (g = R^T R).  A direction whose pivot falls below
+// 1e-24 of the largest diagonal entry is dropped (its column of rinv is zero), so rank-deficient blocks stay finite.  Shared by
+// the kernel and the host-side Rayleigh-Ritz step so that both see the same Q.
+__host__ __device__ inline void pca_chol_rinv(const double* g, double* rinv) {
+    double R[PCA_NB][PCA_NB];
+    bool dead[PCA_NB];
+    double big = 0.0;
+    for (int a = 0; a < PCA_NB; ++a) big = g[a * PCA_NB + a] > big ? g[a * PCA_NB + a] : big;
+    for (int a = 0; a < PCA_NB; ++a) {
+        double d = g[a * PCA_NB + a];
+        for (int k = 0; k < a; ++k) d -= R[k][a] * R[k][a];
+        dead[a] = !(d > 1e-24 * big);
+        const double inv = dead[a] ? 0.0 : 1.0 / sqrt(d);
+        for (int b = 0; b < PCA_NB; ++b) R[a][b] = 0.0;
+        if (dead[a]) continue;
+        R[a][a] = d * inv;
+        for (int b = a + 1; b < PCA_NB; ++b) {
+            double v = g[a * PCA_NB + b];
+            for (int k = 0; k < a; ++k) v -= R[k][a] * R[k][b];
+            R[a][b] = v * inv;
+        }
+    }
+    for (int a = 0; a < PCA_NB; ++a)
+        for (int b = 0; b < PCA_NB; ++b) rinv[a * PCA_NB + b] = 0.0;
+    for (int a = 0; a < PCA_NB; ++a) {
+        if (dead[a]) continue;
+        rinv[a * PCA_NB + a] = 1.0 / R[a][a];
+        for (int b = a + 1; b < PCA_NB; ++b) {
+            if (dead[b]) continue;
+            double v = 0.0;
+            for (int k = a; k < b; ++k) v += rinv[a * PCA_NB + k] * R[k][b];
+            rinv[a * PCA_NB + b] = -v / R[b][b];
+        }
+    }
+}
+hipError_t launch_pca_power(const float* cov, const double* yprev, const double* gprev, double* ynext, double* gnext, int H,
+                            hipStream_t stream);
+hipError_t launch_pca_project(const float* tok, const float* mean, const float* comp, float* proj, int P, int H,
+                              hipStream_t stream);
+
 // debugging aid: what ds_read_b64_tr_b16 returns per lane for addr = lane*8 over an LDS image holding its own
 // element index (out: [64][4] int16)
 hipError_t launch_probe_tr16(int16_t* out, hipStream_t stream);

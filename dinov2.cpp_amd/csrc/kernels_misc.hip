@@ -490,4 +490,105 @@ hipError_t launch_pca_prepare(const float* tok, float* mean, void* xt, int P, in
     return hipGetLastError();
 }
 
+// One step of the block (subspace) iteration for the leading eigenvectors of the symmetric cov [H, H]:
+//     Q = Y_prev R^-1   (R from the Cholesky factorisation of Y_prev^T Y_prev: CholeskyQR),    Y_next = cov Q
+// in ONE launch and without a grid-wide dependency inside it: every workgroup rebuilds the 8 x 8 Gram matrix from the
+// per-workgroup partial sums the previous launch left in g_prev (fixed summation order: deterministic), factors it, applies
+// R^-1 to its own 16 rows of cov Y_prev (cov (Y R^-1) = (cov Y) R^-1), and leaves its partial Gram sums of Y_next in g_next.
+// Y is double [H][8]; cov stays f32 and stays in L2 / MALL across the iterations (4 MB at H = 1024).
+__global__ __launch_bounds__(256) void pca_power_kernel(const float* __restrict__ cov, const double* __restrict__ yprev,
+                                                        const double* __restrict__ gprev, double* __restrict__ ynext,
+                                                        double* __restrict__ gnext, int H) {
+    __shared__ double gs[64], rinv[64], ys[PCA_ROWS][PCA_NB];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (t < 64) {
+        double s = 0.0;
+        for (int blk = 0; blk < (int)gridDim.x; ++blk) s += gprev[(size_t)blk * 64 + t];
+        gs[t] = s;
+    }
+    __syncthreads();
+    if (t == 0) pca_chol_rinv(gs, rinv);
+    // rows of this wave: four, against one pass over Y_prev
+    const int i0 = blockIdx.x * PCA_ROWS + w * 4;
+    const float* crow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) crow[r] = cov + (size_t)min(i0 + r, H - 1) * H;
+    double acc[4][PCA_NB];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < PCA_NB; ++c) acc[r][c] = 0.0;
+    for (int j = lane; j < H; j += 64) {
+        double y[PCA_NB];
+        const double2* yp = (const double2*)(yprev + (size_t)j * PCA_NB);
+#pragma unroll
+        for (int c = 0; c < PCA_NB / 2; ++c) {
+            const double2 v = yp[c];
+            y[2 * c] = v.x;
+            y[2 * c + 1] = v.y;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double cij = (double)crow[r][j];
+#pragma unroll
+            for (int c = 0; c < PCA_NB; ++c) acc[r][c] = fma(cij, y[c], acc[r][c]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < PCA_NB; ++c) acc[r][c] = wave_sum_f64(acc[r][c]);
+    __syncthreads();  // rinv ready
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double q = 0.0;  // lane b < 8 owns column b:  (t R^-1)[b] = sum_{a <= b} t[a] rinv[a][b]
+#pragma unroll
+        for (int a = 0; a < PCA_NB; ++a) q = fma(acc[r][a], lane < PCA_NB ? rinv[a * PCA_NB + lane] : 0.0, q);
+        const bool live = i0 + r < H;
+        if (lane < PCA_NB) {
+            if (live) ynext[(size_t)(i0 + r) * PCA_NB + lane] = q;
+            ys[w * 4 + r][lane] = live ? q : 0.0;
+        }
+    }
+    __syncthreads();
+    if (t < 64) {
+        const int a = t >> 3, b = t & 7;
+        double s = 0.0;
+#pragma unroll
+        for (int r = 0; r < PCA_ROWS; ++r) s = fma(ys[r][a], ys[r][b], s);
+        gnext[(size_t)blockIdx.x * 64 + t] = s;
+    }
+}
+
+hipError_t launch_pca_power(const float* cov, const double* yprev, const double* gprev, double* ynext, double* gnext, int H,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(pca_power_kernel, dim3(pca_blocks(H)), dim3(256), 0, st, cov, yprev, gprev, ynext, gnext, H);
+    return hipGetLastError();
+}
+
+// proj[p][c] = sum_j (tok[p][j] - mean[j]) comp[c][j], c < 3: one wave per token row, double accumulation
+__global__ __launch_bounds__(256) void pca_project_kernel(const float* __restrict__ tok, const float* __restrict__ mean,
+                                                          const float* __restrict__ comp, float* __restrict__ proj, int P, int H) {
+    const int lane = threadIdx.x & 63, p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int j = lane; j < H; j += 64) {
+        const double d = (double)tok[(size_t)p * H + j] - (double)mean[j];
+        a0 = fma(d, (double)comp[j], a0);
+        a1 = fma(d, (double)comp[H + j], a1);
+        a2 = fma(d, (double)comp[2 * H + j], a2);
+    }
+    a0 = wave_sum_f64(a0); a1 = wave_sum_f64(a1); a2 = wave_sum_f64(a2);
+    if (lane == 0) {
+        proj[(size_t)p * 3] = (float)a0;
+        proj[(size_t)p * 3 + 1] = (float)a1;
+        proj[(size_t)p * 3 + 2] = (float)a2;
+    }
+}
+
+hipError_t launch_pca_project(const float* tok, const float* mean, const float* comp, float* proj, int P, int H, hipStream_t st) {
+    hipLaunchKernelGGL(pca_project_kernel, dim3((P + 3) / 4), dim3(256), 0, st, tok, mean, comp, proj, P, H);
+    return hipGetLastError();
+}
+
 }  // namespace dinov2

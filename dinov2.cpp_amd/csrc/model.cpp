@@ -9,6 +9,7 @@
 #include "model.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -768,6 +769,7 @@ extern "C" void dinov2_hip_session_free(dinov2_hip_session* s) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (s->ws) (void)hipFree(s->ws);
     if (s->raw) (void)hipFree(s->raw);
+    if (s->pca_buf) (void)hipFree(s->pca_buf);
     if (s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -869,6 +871,11 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
     if (rc != DINOV2_HIP_OK) return rc;
     rc = forward_maybe_graph(s, img, B, h, w, layout, classify, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;
+    {  // what dinov2_hip_pca3(tokens = NULL) works on: the patch rows of image 0 in `fin`
+        const Dims dd = dims_of(m, B, h, w);
+        s->last_first = classify ? 1 : 1 + (int)m->hp.num_register_tokens;
+        s->last_patches = dd.T - s->last_first;
+    }
     if (!out) return DINOV2_HIP_OK;
 
     const Dims d = dims_of(m, B, h, w);
@@ -939,165 +946,194 @@ extern "C" int dinov2_hip_debug_hidden(dinov2_hip_session* s, const dinov2_hip_i
     return DINOV2_HIP_OK;
 }
 
+// =============================================================================================================
+// PCA of patch tokens (SURVEY 8(f) next-2; cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project, inference.cpp:76-81)
+// =============================================================================================================
 namespace dinov2 {
-// comp [3, H] = the three leading unit eigenvectors of the symmetric matrix cov [H, H] (H >= 4), by variance, each with its
-// largest loading positive.  Host code; also reachable through dinov2_hip_op_eig3 for the CPU tests.
-void top3_eigenvectors(const float* cov_p, int H, double* comp) {
-    const float* cov = cov_p;
-    // three leading eigenvectors of the symmetric H x H matrix: subspace iteration with a block of NB >= 3 vectors (the
-    // wanted three then converge like (lambda_{NB+1} / lambda_3)^k) and a Rayleigh-Ritz step per iteration, all in double
-    const int NB = std::min(8, H);
-    constexpr int LD = 8;  // row stride of Q / Y: fixed so that the inner loops below vectorise; columns >= NB stay zero
-    std::vector<double> Q((size_t)H * LD, 0.0), Y((size_t)H * LD, 0.0), Bm((size_t)NB * NB), V((size_t)NB * NB);
-    for (int j = 0; j < H; ++j)
-        for (int c = 0; c < NB; ++c) Q[(size_t)j * LD + c] = std::sin(0.37 * (j + 1) * (c + 1)) + (c == j % NB ? 0.5 : 0.0);
-    auto orthonormalise = [&](std::vector<double>& M) {  // modified Gram-Schmidt, twice for safety
-        for (int pass = 0; pass < 2; ++pass)
-            for (int c = 0; c < NB; ++c) {
-                for (int k = 0; k < c; ++k) {
-                    double d = 0;
-                    for (int j = 0; j < H; ++j) d += M[(size_t)j * LD + k] * M[(size_t)j * LD + c];
-                    for (int j = 0; j < H; ++j) M[(size_t)j * LD + c] -= d * M[(size_t)j * LD + k];
-                }
-                double n = 0;
-                for (int j = 0; j < H; ++j) n += M[(size_t)j * LD + c] * M[(size_t)j * LD + c];
-                n = std::sqrt(n);
-                if (n > 0)
-                    for (int j = 0; j < H; ++j) M[(size_t)j * LD + c] /= n;
-            }
-    };
-    auto multiply = [&]() {  // Y = C Q, Bm = Q^T Y
-        std::fill(Bm.begin(), Bm.end(), 0.0);
-        for (int i = 0; i < H; ++i) {
-            double y[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const float* row = cov + (size_t)i * H;
-            for (int j = 0; j < H; ++j) {
-                const double cij = row[j];
-                for (int c = 0; c < LD; ++c) y[c] += cij * Q[(size_t)j * LD + c];
-            }
-            for (int c = 0; c < LD; ++c) Y[(size_t)i * LD + c] = y[c];
-            for (int r = 0; r < NB; ++r)
-                for (int c = 0; c < NB; ++c) Bm[(size_t)r * NB + c] += Q[(size_t)i * LD + r] * y[c];
-        }
-    };
-    int order[8];
-    auto ritz = [&]() {  // cyclic Jacobi on the NB x NB matrix Bm: eigenvalues on its diagonal, eigenvectors in V's columns
-        std::fill(V.begin(), V.end(), 0.0);
-        for (int k = 0; k < NB; ++k) V[(size_t)k * NB + k] = 1.0;
-        for (int r = 0; r < NB; ++r)
-            for (int c = r + 1; c < NB; ++c) Bm[(size_t)r * NB + c] = Bm[(size_t)c * NB + r] = 0.5 * (Bm[(size_t)r * NB + c] + Bm[(size_t)c * NB + r]);
-        for (int sweep = 0; sweep < 40; ++sweep) {
-            double off = 0, diag = 0;
-            for (int r = 0; r < NB; ++r)
-                for (int c = 0; c < NB; ++c) (r == c ? diag : off) += Bm[(size_t)r * NB + c] * Bm[(size_t)r * NB + c];
-            if (off <= 1e-30 * diag) break;
-            for (int pp = 0; pp < NB - 1; ++pp)
-                for (int q = pp + 1; q < NB; ++q) {
-                    const double apq = Bm[(size_t)pp * NB + q];
-                    if (apq == 0.0) continue;
-                    const double th = 0.5 * std::atan2(2 * apq, Bm[(size_t)q * NB + q] - Bm[(size_t)pp * NB + pp]);
-                    const double c = std::cos(th), sn = std::sin(th);
-                    for (int k = 0; k < NB; ++k) {
-                        const double x = Bm[(size_t)k * NB + pp], y = Bm[(size_t)k * NB + q];
-                        Bm[(size_t)k * NB + pp] = c * x - sn * y; Bm[(size_t)k * NB + q] = sn * x + c * y;
-                    }
-                    for (int k = 0; k < NB; ++k) {
-                        const double x = Bm[(size_t)pp * NB + k], y = Bm[(size_t)q * NB + k];
-                        Bm[(size_t)pp * NB + k] = c * x - sn * y; Bm[(size_t)q * NB + k] = sn * x + c * y;
-                    }
-                    for (int k = 0; k < NB; ++k) {
-                        const double x = V[(size_t)k * NB + pp], y = V[(size_t)k * NB + q];
-                        V[(size_t)k * NB + pp] = c * x - sn * y; V[(size_t)k * NB + q] = sn * x + c * y;
-                    }
-                }
-        }
-        for (int k = 0; k < NB; ++k) order[k] = k;
-        std::sort(order, order + NB, [&](int x, int y) { return Bm[(size_t)x * NB + x] > Bm[(size_t)y * NB + y]; });
-    };
-    orthonormalise(Q);
-    double prev[3] = {0, 0, 0};
-    for (int it = 0; it < 300; ++it) {
-        multiply();
-        ritz();
-        bool done = it > 2;
-        for (int c = 0; c < 3; ++c) {
-            const double ev = Bm[(size_t)order[c] * NB + order[c]];
-            if (std::fabs(ev - prev[c]) > 1e-9 * std::fabs(Bm[(size_t)order[0] * NB + order[0]])) done = false;
-            prev[c] = ev;
-        }
-        if (done) break;  // Q (not yet advanced) with this V is the converged Ritz basis
-        Q.swap(Y);
-        orthonormalise(Q);
+// Rayleigh-Ritz step on the host for the device-side block iteration (pca_power_kernel): from Y_prev [H][8], the per-workgroup
+// Gram partials of Y_prev (g_parts [nparts][64]) and Y_next = cov Q [H][8] with Q = Y_prev R^-1, the eigen-decomposition of
+// the 8 x 8 matrix Q^T cov Q.  evals [3]: the three largest Ritz values; comp [3][H] (may be null): their Ritz vectors Q v,
+// unit length, largest loading positive.
+void pca_ritz(const double* yprev, const double* ynext, const double* g_parts, int nparts, int H, double* evals, double* comp) {
+    constexpr int NB = PCA_NB;
+    double G[NB * NB], rinv[NB * NB], Bm[NB * NB] = {0}, V[NB * NB] = {0};
+    for (int t = 0; t < NB * NB; ++t) {
+        double s = 0.0;
+        for (int blk = 0; blk < nparts; ++blk) s += g_parts[(size_t)blk * NB * NB + t];
+        G[t] = s;
     }
+    pca_chol_rinv(G, rinv);
+    std::vector<double> Q((size_t)H * NB);
+    for (int j = 0; j < H; ++j)
+        for (int b = 0; b < NB; ++b) {
+            double q = 0.0;
+            for (int a2 = 0; a2 <= b; ++a2) q += yprev[(size_t)j * NB + a2] * rinv[a2 * NB + b];
+            Q[(size_t)j * NB + b] = q;
+        }
+    for (int j = 0; j < H; ++j)
+        for (int r = 0; r < NB; ++r)
+            for (int c = 0; c < NB; ++c) Bm[r * NB + c] += Q[(size_t)j * NB + r] * ynext[(size_t)j * NB + c];
+    for (int r = 0; r < NB; ++r)
+        for (int c = r + 1; c < NB; ++c) Bm[r * NB + c] = Bm[c * NB + r] = 0.5 * (Bm[r * NB + c] + Bm[c * NB + r]);
+    for (int k = 0; k < NB; ++k) V[k * NB + k] = 1.0;
+    for (int sweep = 0; sweep < 50; ++sweep) {  // cyclic Jacobi: eigenvalues on Bm's diagonal, eigenvectors in V's columns
+        double off = 0, diag = 0;
+        for (int r = 0; r < NB; ++r)
+            for (int c = 0; c < NB; ++c) (r == c ? diag : off) += Bm[r * NB + c] * Bm[r * NB + c];
+        if (off <= 1e-30 * diag) break;
+        for (int p = 0; p < NB - 1; ++p)
+            for (int q = p + 1; q < NB; ++q) {
+                const double apq = Bm[p * NB + q];
+                if (apq == 0.0) continue;
+                const double th = 0.5 * std::atan2(2 * apq, Bm[q * NB + q] - Bm[p * NB + p]);
+                const double c = std::cos(th), sn = std::sin(th);
+                for (int k = 0; k < NB; ++k) {
+                    const double x = Bm[k * NB + p], y = Bm[k * NB + q];
+                    Bm[k * NB + p] = c * x - sn * y; Bm[k * NB + q] = sn * x + c * y;
+                }
+                for (int k = 0; k < NB; ++k) {
+                    const double x = Bm[p * NB + k], y = Bm[q * NB + k];
+                    Bm[p * NB + k] = c * x - sn * y; Bm[q * NB + k] = sn * x + c * y;
+                }
+                for (int k = 0; k < NB; ++k) {
+                    const double x = V[k * NB + p], y = V[k * NB + q];
+                    V[k * NB + p] = c * x - sn * y; V[k * NB + q] = sn * x + c * y;
+                }
+            }
+    }
+    int order[NB];
+    for (int k = 0; k < NB; ++k) order[k] = k;
+    std::sort(order, order + NB, [&](int x, int y) { return Bm[x * NB + x] > Bm[y * NB + y]; });
     for (int c = 0; c < 3; ++c) {
         const int o = order[c];
+        evals[c] = Bm[o * NB + o];
+        if (!comp) continue;
         int big = 0;
         double nrm = 0;
         for (int j = 0; j < H; ++j) {
             double v = 0;
-            for (int k = 0; k < NB; ++k) v += Q[(size_t)j * LD + k] * V[(size_t)k * NB + o];
+            for (int k = 0; k < NB; ++k) v += Q[(size_t)j * NB + k] * V[k * NB + o];
             comp[(size_t)c * H + j] = v;
             nrm += v * v;
             if (std::fabs(v) > std::fabs(comp[(size_t)c * H + big])) big = j;
         }
-        const double sc = (comp[(size_t)c * H + big] < 0 ? -1.0 : 1.0) / std::sqrt(nrm);  // unit length, largest loading positive
+        const double sc = nrm > 0 ? (comp[(size_t)c * H + big] < 0 ? -1.0 : 1.0) / std::sqrt(nrm) : 0.0;
         for (int j = 0; j < H; ++j) comp[(size_t)c * H + j] *= sc;
     }
 }
 }  // namespace dinov2
 
-// =============================================================================================================
-// PCA of patch tokens (SURVEY 8(f) next-2; cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project, inference.cpp:76-81)
-// =============================================================================================================
 extern "C" int dinov2_hip_pca3(dinov2_hip_session* s, const float* tokens, int32_t P, int32_t H, int32_t on_device,
                                float* components, float* mean, float* projection, char* err, size_t errlen) {
-    if (!s || !tokens || P < 4 || H < 4 || H > 4096) {
-        set_err(err, errlen, "pca3: need tokens [P >= 4, 4 <= H <= 4096]");
+    if (!s || P < 4 || H < 8 || H > 4096) {
+        set_err(err, errlen, "pca3: need tokens [P >= 4, 8 <= H <= 4096]");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    if (!tokens && (s->last_patches != P || (int)s->model->hp.hidden_size != H || !s->fin)) {
+        set_err(err, errlen, "pca3: tokens == NULL means the last forward's patch tokens of image 0, which are [%d, %d]",
+                s->last_patches, (int)s->model->hp.hidden_size);
         return DINOV2_HIP_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(s->model->device));
     hipStream_t st = s->stream;
+    static const bool trace = getenv("DINOV2_HIP_PCA_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
+    double t_setup = 0, t_iter = 0;
+    int n_steps = 0;
     const int Ppad = (P + 127) / 128 * 128;  // K of the covariance GEMM: multiple of 64 with an even K / 64
+    const int nb = pca_blocks(H);
     const size_t n_tok = (size_t)P * H * 4, n_xt = (size_t)H * Ppad * 2, n_cov = (size_t)H * H * 4, n_mean = (size_t)H * 4;
-    const size_t need = align_up(n_tok, 256) + align_up(n_xt, 256) + align_up(n_cov, 256) + align_up(n_mean, 256);
-    char* buf = nullptr;
-    HIP_TRY(hipMalloc((void**)&buf, need));
-    struct Free { char* p; ~Free() { (void)hipFree(p); } } guard{buf};
-    float* d_tok = (float*)buf;
-    char* d_xt = buf + align_up(n_tok, 256);
-    float* d_cov = (float*)(d_xt + align_up(n_xt, 256));
-    float* d_mean = (float*)((char*)d_cov + align_up(n_cov, 256));
+    const size_t n_y = (size_t)H * PCA_NB * 8, n_g = (size_t)nb * 64 * 8, n_comp = (size_t)3 * H * 4, n_proj = (size_t)P * 3 * 4;
+    size_t need = 0;
+    auto take = [&](size_t bytes) { const size_t off = need; need += align_up(bytes, 256); return off; };
+    const size_t o_tok = take(tokens && !on_device ? n_tok : 0), o_xt = take(n_xt), o_cov = take(n_cov), o_mean = take(n_mean);
+    const size_t o_y[3] = {take(n_y), take(n_y), take(n_y)}, o_g[3] = {take(n_g), take(n_g), take(n_g)};
+    const size_t o_comp = take(n_comp), o_proj = take(n_proj);
+    if (need > s->pca_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (s->pca_buf) HIP_TRY(hipFree(s->pca_buf));
+        s->pca_buf = nullptr;
+        s->pca_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&s->pca_buf, need));
+        s->pca_bytes = need;
+    }
+    char* buf = s->pca_buf;
+    float* d_cov = (float*)(buf + o_cov);
+    float* d_mean = (float*)(buf + o_mean);
+    float* d_comp = (float*)(buf + o_comp);
+    float* d_proj = (float*)(buf + o_proj);
+    double* d_y[3] = {(double*)(buf + o_y[0]), (double*)(buf + o_y[1]), (double*)(buf + o_y[2])};
+    double* d_g[3] = {(double*)(buf + o_g[0]), (double*)(buf + o_g[1]), (double*)(buf + o_g[2])};
     const float* tok = tokens;
-    if (!on_device) {
-        HIP_TRY(hipMemcpyAsync(d_tok, tokens, n_tok, hipMemcpyHostToDevice, st));
-        tok = d_tok;
+    if (!tokens) {
+        tok = s->fin + (size_t)s->last_first * H;
+    } else if (!on_device) {
+        HIP_TRY(hipMemcpyAsync(buf + o_tok, tokens, n_tok, hipMemcpyHostToDevice, st));
+        tok = (const float*)(buf + o_tok);
     }
-    HIP_TRY(launch_pca_prepare(tok, d_mean, d_xt, P, H, Ppad, st));
+    HIP_TRY(launch_pca_prepare(tok, d_mean, buf + o_xt, P, H, Ppad, st));
     GemmArgs a{};  // P * C = Xt Xt^T: both operands are the same [H, Ppad] matrix
-    a.A = d_xt; a.W = d_xt; a.out = d_cov; a.M = H; a.N = H; a.K = Ppad; a.ldo = H;
+    a.A = buf + o_xt; a.W = buf + o_xt; a.out = d_cov; a.M = H; a.N = H; a.K = Ppad; a.ldo = H;
     HIP_TRY(launch_gemm(DT_F16, EPI_PLAIN_F32, a, st));
-    std::vector<float> cov((size_t)H * H), mu((size_t)H), host_tok;
-    HIP_TRY(hipMemcpyAsync(cov.data(), d_cov, n_cov, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(mu.data(), d_mean, n_mean, hipMemcpyDeviceToHost, st));
-    if (on_device && projection) {
-        host_tok.resize((size_t)P * H);
-        HIP_TRY(hipMemcpyAsync(host_tok.data(), tokens, n_tok, hipMemcpyDeviceToHost, st));
-    }
-    HIP_TRY(hipStreamSynchronize(st));
 
-    std::vector<double> comp((size_t)3 * H);
-    dinov2::top3_eigenvectors(cov.data(), H, comp.data());
-    if (components)
-        for (size_t i = 0; i < comp.size(); ++i) components[i] = (float)comp[i];
-    if (mean) std::memcpy(mean, mu.data(), n_mean);
-    if (projection) {
-        const float* t = on_device ? host_tok.data() : tokens;
-        for (int p = 0; p < P; ++p)
-            for (int c = 0; c < 3; ++c) {
-                double d = 0;
-                for (int j = 0; j < H; ++j) d += ((double)t[(size_t)p * H + j] - mu[(size_t)j]) * comp[(size_t)c * H + j];
-                projection[(size_t)p * 3 + c] = (float)d;
-            }
+    // start block (slot 2): a fixed, well-conditioned pattern; its Gram matrix goes into workgroup 0's partial slot
+    std::vector<double> y0((size_t)H * PCA_NB), g0((size_t)nb * 64, 0.0);
+    for (int j = 0; j < H; ++j)
+        for (int c = 0; c < PCA_NB; ++c) y0[(size_t)j * PCA_NB + c] = std::sin(0.37 * (j + 1) * (c + 1)) + (c == j % PCA_NB ? 0.5 : 0.0);
+    for (int j = 0; j < H; ++j)
+        for (int r = 0; r < PCA_NB; ++r)
+            for (int c = 0; c < PCA_NB; ++c) g0[(size_t)r * PCA_NB + c] += y0[(size_t)j * PCA_NB + r] * y0[(size_t)j * PCA_NB + c];
+    HIP_TRY(hipMemcpyAsync(d_y[2], y0.data(), n_y, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_g[2], g0.data(), n_g, hipMemcpyHostToDevice, st));
+
+    if (trace) { (void)hipStreamSynchronize(st); t_setup = since(); }
+    // block iteration on the device, Rayleigh-Ritz + convergence test on the host every CHECK steps
+    // (steep spectra -- real images -- converge within the first two or three checks; a flat one needs a few hundred steps)
+    constexpr int MAX_CHECKS = 28;
+    std::vector<double> yp((size_t)H * PCA_NB), yn((size_t)H * PCA_NB), gp((size_t)nb * 64), comp((size_t)3 * H);
+    double ev[3] = {0, 0, 0}, prev[3] = {0, 0, 0};
+    int src = 2;  // slot holding Y_prev / its Gram partials
+    for (int chk = 0; chk < MAX_CHECKS; ++chk) {
+        const int CHECK = chk < 4 ? 8 : 16;
+        int dst = 0;
+        for (int it = 0; it < CHECK; ++it) {
+            dst = src == 0 ? 1 : 0;
+            HIP_TRY(launch_pca_power(d_cov, d_y[src], d_g[src], d_y[dst], d_g[dst], H, st));
+            if (it + 1 < CHECK) src = dst;
+        }
+        // here: src = Y_prev of the last step, dst = Y_next
+        HIP_TRY(hipMemcpyAsync(yp.data(), d_y[src], n_y, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(gp.data(), d_g[src], n_g, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(yn.data(), d_y[dst], n_y, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        dinov2::pca_ritz(yp.data(), yn.data(), gp.data(), nb, H, ev, nullptr);
+        n_steps += CHECK;
+        bool done = chk > 0;
+        for (int c = 0; c < 3; ++c) {
+            if (!(std::fabs(ev[c] - prev[c]) <= 1e-8 * std::fabs(ev[0]))) done = false;
+            prev[c] = ev[c];
+        }
+        if (done || !(ev[0] > 0.0)) break;  // converged, or a zero / non-finite covariance: nothing to iterate on
+        src = dst;
     }
+    t_iter = since();
+    if (!std::isfinite(ev[0]) || !std::isfinite(ev[2])) {
+        set_err(err, errlen, "pca3: non-finite covariance (tokens beyond the f16 range?)");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    dinov2::pca_ritz(yp.data(), yn.data(), gp.data(), nb, H, ev, comp.data());
+    std::vector<float> compf(comp.begin(), comp.end());
+    if (projection) {
+        HIP_TRY(hipMemcpyAsync(d_comp, compf.data(), n_comp, hipMemcpyHostToDevice, st));
+        HIP_TRY(launch_pca_project(tok, d_mean, d_comp, d_proj, P, H, st));
+        HIP_TRY(hipMemcpyAsync(projection, d_proj, n_proj, hipMemcpyDeviceToHost, st));
+    }
+    if (mean) HIP_TRY(hipMemcpyAsync(mean, d_mean, n_mean, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (components) std::memcpy(components, compf.data(), n_comp);
+    if (trace)
+        fprintf(stderr, "pca3: P %d H %d: means + covariance %.3f ms, %d steps %.3f ms, total %.3f ms (eigenvalues %.4g %.4g %.4g)\n", P, H,
+                t_setup, n_steps, t_iter - t_setup, since(), ev[0], ev[1], ev[2]);
     return DINOV2_HIP_OK;
 }

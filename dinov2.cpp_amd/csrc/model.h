@@ -50,6 +50,9 @@ struct dinov2_hip_session {
     size_t ws_bytes = 0;
     uint8_t* raw = nullptr;  // raw 8-bit images for DINOV2_HIP_U8_BGR_HWC inputs
     size_t raw_bytes = 0;
+    char* pca_buf = nullptr;  // dinov2_hip_pca3's device scratch, grown on demand
+    size_t pca_bytes = 0;
+    int last_first = 0, last_patches = 0;  // rows [last_first, last_first + last_patches) of image 0 in `fin`: its patch tokens
     // carved views (valid for cur_* shape)
     int cur_b = 0, cur_h = 0, cur_w = 0;
     float *img = nullptr, *x = nullptr, *fin = nullptr, *feat = nullptr, *logits = nullptr, *probs = nullptr,

@@ -257,10 +257,10 @@ extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t
     return ms / iters;
 }
 
-namespace dinov2 { void top3_eigenvectors(const float* cov, int H, double* comp); }
-// host-only: the eigen-solve behind dinov2_hip_pca3, for the CPU test-suite
-extern "C" int dinov2_hip_op_eig3(const float* cov, int32_t H, double* comp) {
-    if (!cov || !comp || H < 4) return DINOV2_HIP_ERR_INVALID;
-    dinov2::top3_eigenvectors(cov, H, comp);
-    return 0;
+namespace dinov2 { void pca_ritz(const double* yprev, const double* ynext, const double* g_parts, int nparts, int H, double* evals, double* comp); }
+// host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3, for the CPU test-suite
+extern "C" int dinov2_hip_op_pca_ritz(const double* yprev, const double* ynext, const double* gram, int32_t H, double* evals, double* comp) {
+    if (!yprev || !ynext || !gram || !evals || H < 8) return DINOV2_HIP_ERR_INVALID;
+    dinov2::pca_ritz(yprev, ynext, gram, 1, H, evals, comp);
+    return DINOV2_HIP_OK;
 }

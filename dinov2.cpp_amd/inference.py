@@ -22,9 +22,14 @@ def pca_visual(patch_tokens: np.ndarray, rows: int, cols: int, out_h: int, out_w
     """cv::PCA(DATA_AS_ROW, 3) + project + normalize(0, 255, NORM_MINMAX, CV_8U) + reshape + resize(INTER_NEAREST)
     (inference.cpp:76-92).  Returns uint8 [out_h, out_w, 3].  Eigenvector signs are a free choice in any PCA; here each
     component is oriented so that its largest-magnitude loading is positive.  With a `session` the means and the covariance
-    are computed on the device (dinov2_hip_pca3); without one this is the host tool's numpy path."""
+    are computed on the device (dinov2_hip_pca3); without one this is the host tool's numpy path.  With a session,
+    `patch_tokens` may also be the hidden size H alone: the PCA then runs on the patch tokens the session's last predict()
+    left on the device."""
     if session is not None:
-        _, _, proj = session.pca3(patch_tokens)
+        if isinstance(patch_tokens, (int, np.integer)):
+            _, _, proj = session.pca3(None, (rows * cols, int(patch_tokens)))
+        else:
+            _, _, proj = session.pca3(patch_tokens)
         return _render(proj, rows, cols, out_h, out_w)
     try:  # a 2 170 x 1 024 problem spread over hundreds of BLAS threads is slower than over eight
         from threadpoolctl import threadpool_limits
@@ -139,7 +144,7 @@ def main(argv=None) -> int:
     sess.sync()
     t0 = time.perf_counter()
     r = sess.predict(img[None], classify=p.classify, layout=api.U8_BGR_HWC, topk=p.topk if p.classify else 0,
-                     want=("probs",) if p.classify else ("patch_tokens",))
+                     want=("probs",) if p.classify else ())  # features: the patch tokens stay on the device for the PCA
     sess.sync()
     print(f"main: graph computation took {int(round((time.perf_counter() - t0) * 1e3))} ms", file=sys.stderr)
     if p.classify:
@@ -149,7 +154,7 @@ def main(argv=None) -> int:
                 print(f" > {model.id2label.get(int(i), str(int(i)))} : {pr:.2f}")
         return 0
     rows, cols = oh // hp.patch_size, ow // hp.patch_size
-    vis = pca_visual(r["patch_tokens"][0], rows, cols, oh, ow, session=sess)
+    vis = pca_visual(hp.hidden_size, rows, cols, oh, ow, session=sess)
     try:
         Image.fromarray(np.ascontiguousarray(vis[:, :, ::-1])).save(p.image_out)  # stored BGR like the cv::Mat -> RGB file
         print(f"main: Saved image to: {p.image_out}", file=sys.stderr)

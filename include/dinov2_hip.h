@@ -134,10 +134,14 @@ int dinov2_hip_preprocess_size(int32_t mode, int32_t height, int32_t width, int3
 int dinov2_hip_preprocess(int32_t mode, const uint8_t *bgr, int32_t height, int32_t width, int32_t patch, float *out);
 
 /* -- feature post-processing (replaces cv::PCA(tokens, noArray(), DATA_AS_ROW, 3) + project of
- *    inference.cpp:76-81).  tokens: [P, H] f32, host or device.  Column means and the H x H covariance are computed on the
- *    device (the covariance as one MFMA GEMM of the centred, transposed f16 tokens with themselves); the three leading
- *    eigenvectors by subspace iteration on the host.  Outputs (host, any may be NULL): components [3, H] unit vectors sorted by
- *    variance, each oriented so that its largest loading is positive; mean [H]; projection [P, 3] = (tokens - mean) components^T. */
+ *    inference.cpp:76-81).  tokens: [P, H] f32 (P >= 4, 8 <= H <= 4096, |x| within the f16 range), a host pointer, a device
+ *    pointer (on_device = 1), or NULL = the patch tokens of image 0 that the session's last dinov2_hip_predict left on the
+ *    device (P and H must be theirs) -- the realtime loop's case: nothing but the [P, 3] projection crosses PCIe.
+ *    On the device: column means, the H x H covariance (one MFMA GEMM of the centred, transposed f16 tokens with themselves),
+ *    a block iteration (8 vectors, CholeskyQR, one launch per step) for the leading eigenvectors, and the projection; on the
+ *    host only the 8 x 8 Rayleigh-Ritz problem.  Deterministic.  Outputs (host, any may be NULL): components [3, H] unit
+ *    vectors sorted by variance, each oriented so that its largest loading is positive; mean [H]; projection [P, 3] =
+ *    (tokens - mean) components^T. */
 int dinov2_hip_pca3(dinov2_hip_session *session, const float *tokens, int32_t P, int32_t H, int32_t on_device,
                     float *components, float *mean, float *projection, char *err, size_t errlen);
 

@@ -41,9 +41,10 @@ int dinov2_hip_op_probe_tr16(int16_t *out256);
 float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters);
 float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t nh, int32_t iters);
 
-/* host-only: the eigen-solve behind dinov2_hip_pca3 -- comp [3, H] (double) = three leading unit eigenvectors of the symmetric
- * cov [H, H] (H >= 4), sorted by eigenvalue, each with its largest loading positive */
-int dinov2_hip_op_eig3(const float *cov, int32_t H, double *comp);
+/* host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3.  yprev [H][8] (any full-rank block), gram [8][8] = yprev^T yprev,
+ * ynext [H][8] = cov * (yprev R^-1) with gram = R^T R  ->  evals [3] largest Ritz values of cov on span(yprev), comp [3][H] their
+ * unit Ritz vectors, each with its largest loading positive (H >= 8) */
+int dinov2_hip_op_pca_ritz(const double *yprev, const double *ynext, const double *gram, int32_t H, double *evals, double *comp);
 
 #ifdef __cplusplus
 }

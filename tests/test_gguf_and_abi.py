@@ -295,21 +295,32 @@ def test_native_quantize_equals_python_tool(api, pkg, golden_dir, tmp_path, ityp
     assert api.lib().dinov2_hip_quantize(b"/nonexistent.gguf", str(tmp_path / "x.gguf").encode(), 8, err, 256) == 1
 
 
-@pytest.mark.parametrize("H,decay", [(4, 0.5), (7, 0.6), (32, 0.7), (384, 0.9), (1024, 0.95)])
-def test_pca_eigen_solve_matches_eigh(pkg, H, decay):
-    """The host half of dinov2_hip_pca3 (block subspace iteration + Rayleigh-Ritz, csrc/model.cpp top3_eigenvectors) against
-    numpy's eigh on symmetric matrices with a geometric spectrum: same three leading eigenvectors, unit length, sign convention
-    'largest loading positive'.  No device call."""
+@pytest.mark.parametrize("H", [8, 33, 384, 1024])
+def test_pca_ritz_step_matches_eigh(pkg, H):
+    """The host half of dinov2_hip_pca3 (CholeskyQR of the block + 8 x 8 Rayleigh-Ritz by Jacobi, csrc/model.cpp pca_ritz): a
+    block spanning the top-8 eigenspace of a symmetric matrix, arbitrarily mixed, must give back its three leading
+    eigenvectors and eigenvalues -- unit length, sign convention 'largest loading positive'.  No device call."""
     api = import_module(pkg.__name__ + ".api")
     rng = np.random.default_rng(H)
     q = np.linalg.qr(rng.standard_normal((H, H)))[0]
-    cov = ((q * (100.0 * decay ** np.arange(H))) @ q.T).astype(np.float32)
-    comp = np.empty((3, H), np.float64)
-    assert api.lib().dinov2_hip_op_eig3(cov.ctypes.data, H, comp.ctypes.data) == 0
-    _, v = np.linalg.eigh(cov.astype(np.float64))
-    ref = v[:, ::-1][:, :3].T
+    w = 100.0 * 0.8 ** np.arange(H)
+    cov = (q * w) @ q.T
+    y = q[:, :8] @ (rng.standard_normal((8, 8)) + 3 * np.eye(8))          # same span, not orthonormal
+    gram = y.T @ y
+    r = np.linalg.cholesky(gram).T                                          # gram = R^T R, R upper with positive diagonal
+    ynext = cov @ (y @ np.linalg.inv(r))
+    evals, comp = np.empty(3), np.empty((3, H))
+    args = [np.ascontiguousarray(a, dtype=np.float64) for a in (y, ynext, gram)]
+    assert api.lib().dinov2_hip_op_pca_ritz(*(a.ctypes.data for a in args), H, evals.ctypes.data, comp.ctypes.data) == 0
+    np.testing.assert_allclose(evals, w[:3], rtol=1e-10)
     np.testing.assert_allclose(np.linalg.norm(comp, axis=1), 1.0, atol=1e-12)
     for k in range(3):
-        assert abs(float(comp[k] @ ref[k])) >= 1 - 1e-7
+        assert abs(float(comp[k] @ q[:, k])) >= 1 - 1e-10
         assert comp[k][np.abs(comp[k]).argmax()] > 0
-    assert api.lib().dinov2_hip_op_eig3(cov.ctypes.data, 3, comp.ctypes.data) != 0
+    # a rank-deficient block (two equal columns) stays finite: the dependent direction is dropped
+    y2 = y.copy(); y2[:, 7] = y2[:, 6]
+    g2 = y2.T @ y2
+    a2 = [np.ascontiguousarray(a, dtype=np.float64) for a in (y2, ynext, g2)]
+    assert api.lib().dinov2_hip_op_pca_ritz(*(a.ctypes.data for a in a2), H, evals.ctypes.data, comp.ctypes.data) == 0
+    assert np.isfinite(evals).all() and np.isfinite(comp).all()
+    assert api.lib().dinov2_hip_op_pca_ritz(*(a.ctypes.data for a in args), 4, evals.ctypes.data, comp.ctypes.data) != 0

@@ -346,9 +346,9 @@ def test_random_shapes_vs_oracle(api, golden_dir, name):
             assert _rel(got["logits"][b], exp["logits"]) <= 1e-3, (B, h, w)
 
 
-@pytest.mark.parametrize("P,H", [(256, 384), (1369, 1024), (2170, 1536), (37, 32), (700, 100)])
+@pytest.mark.parametrize("P,H", [(256, 384), (1369, 1024), (2170, 1536), (37, 32), (700, 100), (12, 8)])
 def test_pca3_matches_svd(api, golden_dir, P, H):
-    """dinov2_hip_pca3 (device means + covariance on the matrix cores, host subspace iteration) against numpy's SVD of the
+    """dinov2_hip_pca3 (device means, covariance on the matrix cores, block iteration, projection; host Rayleigh-Ritz) against numpy's SVD of the
     centred tokens -- the PCA of inference.cpp:76-81.  Tokens get a clear three-direction structure on top of noise, as patch
     tokens have.  Tolerances: |cos| between matching components >= 0.999 (the covariance is accumulated from f16-rounded
     centred tokens), projections within 1% of the largest projection."""
@@ -374,3 +374,20 @@ def test_pca3_matches_svd(api, golden_dir, P, H):
     assert np.abs(np.abs(proj) - np.abs(xc @ ref.T)).max() <= 1e-2 * np.abs(xc @ ref.T).max()
     with pytest.raises(api.DinoError):
         sess.pca3(np.zeros((2, 8), np.float32))
+
+
+def test_pca3_on_resident_tokens(api, golden_dir):
+    """tokens = NULL: the PCA of the patch tokens the last predict left on the device equals, bit for bit, the PCA of the same
+    tokens handed over from the host; a shape that is not theirs is refused."""
+    sess = api.Session(api.Model(os.path.join(golden_dir, "tiny_gelu_reg4.gguf"), classify=False))
+    img = np.random.default_rng(3).standard_normal((2, 3, 84, 112)).astype(np.float32)
+    tok = sess.predict(img, classify=False)["patch_tokens"]
+    P, H = tok.shape[1:]
+    a = sess.pca3(None, (P, H))
+    b = sess.pca3(tok[0])
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    with pytest.raises(api.DinoError):
+        sess.pca3(None, (P + 1, H))
+    again = sess.pca3(tok[0])
+    assert all(np.array_equal(x, y) for x, y in zip(again, b))  # deterministic

@@ -24,17 +24,21 @@ W, H = 854, 480  # FRAME_WIDTH x FRAME_HEIGHT of the reference
 rng = np.random.default_rng(0)
 frames = rng.integers(0, 256, (8, H, W, 3), dtype=np.uint8)
 oh, ow = api.preprocess_size(0, H, W, model.hparams.patch_size)
-t_fwd = t_pca = 0.0
-for i in range(args.frames + 10):
-    f = frames[i % 8][None]
-    t0 = time.perf_counter()
-    r = sess.predict(f, classify=False, layout=api.U8_BGR_HWC, want=("patch_tokens",))
-    t1 = time.perf_counter()
-    vis = inf.pca_visual(r["patch_tokens"][0], oh // 14, ow // 14, oh, ow)
-    t2 = time.perf_counter()
-    if i >= 10:
-        t_fwd += t1 - t0
-        t_pca += t2 - t1
 n = args.frames
-print(f"{args.model}: frame {W}x{H} -> {ow}x{oh} ({(oh // 14) * (ow // 14)} patches); forward incl. H2D/D2H {t_fwd / n * 1e3:.2f} ms, "
-      f"host PCA {t_pca / n * 1e3:.2f} ms -> {n / (t_fwd + t_pca):.1f} frames/s ({n / t_fwd:.1f} without the PCA)")
+Hd = model.hparams.hidden_size
+for label, mode in (("device PCA on resident tokens (dinov2_hip_pca3)", 2), ("device PCA on host tokens", 1), ("host numpy PCA", 0)):
+    t_fwd = t_pca = 0.0
+    for i in range(n + 10):
+        f = frames[i % 8][None]
+        t0 = time.perf_counter()
+        r = sess.predict(f, classify=False, layout=api.U8_BGR_HWC, want=() if mode == 2 else ("patch_tokens",))
+        if mode == 2:
+            sess.sync()
+        t1 = time.perf_counter()
+        vis = inf.pca_visual(Hd if mode == 2 else r["patch_tokens"][0], oh // 14, ow // 14, oh, ow, session=sess if mode else None)
+        t2 = time.perf_counter()
+        if i >= 10:
+            t_fwd += t1 - t0
+            t_pca += t2 - t1
+    print(f"{args.model}: frame {W}x{H} -> {ow}x{oh} ({(oh // 14) * (ow // 14)} patches); forward incl. H2D/D2H {t_fwd / n * 1e3:.2f} ms, "
+          f"{label} {t_pca / n * 1e3:.2f} ms -> {n / (t_fwd + t_pca):.1f} frames/s ({n / t_fwd:.1f} without the PCA)")
