@@ -662,6 +662,7 @@ hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, 
 static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,
                                         hipStream_t st) {
     if (H != nh * 64 || T <= 0 || B <= 0) return hipErrorInvalidValue;
+    if ((size_t)B * T * 3 * H * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // 32-bit staging cursors into qkv
     // 8 waves (256 queries) per workgroup halve the K/V staging per query; 4 waves waste less on the ragged last query
     // block.  DINOV2_HIP_ATTN_WAVES=4|8 overrides (tuning aid).
     static const int forced = [] {

@@ -296,6 +296,8 @@ hipError_t gemm_init() {
 // 221 -> 244 images/s.  DINOV2_HIP_GEMM_SPLIT=0 restricts the choice to A / E, DINOV2_HIP_GEMM_TILE=128|256 forces E / A.
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
+    if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     static const int forced = [] {
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");
         return e ? atoi(e) : 0;

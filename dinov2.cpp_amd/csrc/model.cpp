@@ -840,6 +840,43 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
         w = ow;
         layout = DINOV2_HIP_BGR_HWC;
     }
+    {
+        // The kernels address activations with 32-bit offsets (staging cursors of the GEMMs and of the attention): the widest
+        // activation buffer of one forward must stay below 2^31 bytes.  Larger batches are split here, transparently --
+        // B images are B independent forwards, so the results do not change (ViT-L @518: 190 images per pass).  Passes run
+        // last chunk first, so the session ends up holding chunk 0 (dinov2_hip_pca3's "image 0 of the last predict").
+        const Dims d1 = dims_of(m, 1, h, w);
+        const size_t widest = std::max<size_t>({3 * (size_t)m->hp.hidden_size, (size_t)m->hp.ffn_hidden, (size_t)m->kpe_pad});
+        size_t bmax = std::max<size_t>(1, ((size_t)1 << 31) / ((size_t)d1.T * widest * 2));
+        if (const char* e = getenv("DINOV2_HIP_MAX_CHUNK"))  // testing aid: force the split at small sizes
+            if (atoi(e) > 0) bmax = std::min<size_t>(bmax, (size_t)atoi(e));
+        if ((size_t)B > bmax) {
+            const size_t H = m->hp.hidden_size, C = m->hp.num_classes;
+            const size_t tok_rows = (size_t)(d1.T - (classify ? 1 : 1 + (int)m->hp.num_register_tokens));
+            const size_t in_stride = raw_u8 ? (size_t)in->height * in->width * 3  /* bytes */
+                                            : (size_t)3 * h * w * sizeof(float);
+            const int nchunks = (int)(((size_t)B + bmax - 1) / bmax);
+            for (int c = nchunks - 1; c >= 0; --c) {
+                const size_t b0 = (size_t)c * bmax, bn = std::min<size_t>(bmax, (size_t)B - b0);
+                dinov2_hip_input ci = *in;
+                ci.data = reinterpret_cast<const float*>(reinterpret_cast<const char*>(in->data) + b0 * in_stride);
+                ci.batch = (int32_t)bn;
+                dinov2_hip_output co{};
+                if (out) {
+                    co = *out;
+                    if (out->cls) co.cls = out->cls + b0 * H;
+                    if (out->patch_tokens) co.patch_tokens = out->patch_tokens + b0 * tok_rows * H;
+                    if (out->logits) co.logits = out->logits + b0 * C;
+                    if (out->probs) co.probs = out->probs + b0 * C;
+                    if (out->topk_ids) co.topk_ids = out->topk_ids + b0 * (size_t)out->topk;
+                    if (out->topk_probs) co.topk_probs = out->topk_probs + b0 * (size_t)out->topk;
+                }
+                rc = dinov2_hip_predict(s, &ci, out ? &co : nullptr, flags, err, errlen);
+                if (rc != DINOV2_HIP_OK) return rc;
+            }
+            return DINOV2_HIP_OK;
+        }
+    }
     rc = ensure_workspace(s, B, h, w, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;
     hipStream_t st = s->stream;

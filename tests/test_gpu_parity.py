@@ -391,3 +391,30 @@ def test_pca3_on_resident_tokens(api, golden_dir):
         sess.pca3(None, (P + 1, H))
     again = sess.pca3(tok[0])
     assert all(np.array_equal(x, y) for x, y in zip(again, b))  # deterministic
+
+
+def test_large_batches_are_split_transparently(api, golden_dir, monkeypatch):
+    """dinov2_hip_predict splits a batch whose widest activation buffer would pass 2^31 bytes (the kernels use 32-bit staging
+    offsets).  DINOV2_HIP_MAX_CHUNK forces the split at a small size: same bits as the unsplit call for every output, for host
+    f32 and raw 8-bit inputs, classify and features; and the PCA of the resident tokens still refers to image 0 of the call."""
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    rng = np.random.default_rng(11)
+    img = rng.standard_normal((11, 3, 56, 70)).astype(np.float32)
+    raw = rng.integers(0, 256, (7, 61, 83, 3), dtype=np.uint8)
+    want = ("cls", "patch_tokens", "logits", "probs")
+    ref_c = sess.predict(img, classify=True, topk=3, want=want)
+    ref_f = sess.predict(img, classify=False, want=("cls", "patch_tokens"))
+    ref_r = sess.predict(raw, classify=False, layout=api.U8_BGR_HWC, want=("patch_tokens",))
+    monkeypatch.setenv("DINOV2_HIP_MAX_CHUNK", "4")
+    got_c = sess.predict(img, classify=True, topk=3, want=want)
+    got_f = sess.predict(img, classify=False, want=("cls", "patch_tokens"))
+    P, H = got_f["patch_tokens"].shape[1:]
+    pca_resident = sess.pca3(None, (P, H))
+    got_r = sess.predict(raw, classify=False, layout=api.U8_BGR_HWC, want=("patch_tokens",))
+    for ref, got in ((ref_c, got_c), (ref_f, got_f), (ref_r, got_r)):
+        assert ref.keys() == got.keys()
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), k
+    for a, b in zip(pca_resident, sess.pca3(ref_f["patch_tokens"][0])):
+        assert np.array_equal(a, b)
