@@ -374,6 +374,9 @@ def test_pca3_matches_svd(api, golden_dir, P, H):
     assert np.abs(np.abs(proj) - np.abs(xc @ ref.T)).max() <= 1e-2 * np.abs(xc @ ref.T).max()
     with pytest.raises(api.DinoError):
         sess.pca3(np.zeros((2, 8), np.float32))
+    # degenerate input (all tokens equal: zero covariance) stays finite: zero projection, like cv::PCA on constant data
+    comp0, mean0, proj0 = sess.pca3(np.full((P, H), 2.5, np.float32))
+    assert np.isfinite(comp0).all() and np.array_equal(proj0, np.zeros_like(proj0)) and np.allclose(mean0, 2.5)
 
 
 def test_pca3_on_resident_tokens(api, golden_dir):
