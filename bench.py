@@ -255,7 +255,10 @@ def main():
         del got
 
     out = {
-        "metric": "images/sec (518x518), ViT-L/14 fp16", "value": round(value, 2), "unit": "images/sec",
+        # BASELINE.json's metric on its default configuration; other --model / --size / --dtype runs are labelled as what they are
+        "metric": ("images/sec (518x518), ViT-L/14 fp16" if (args.model, args.size, args.dtype) == ("large", 518, "f16") else
+                   f"images/sec ({args.size}x{args.size}), ViT-{args.model[0].upper()}/14 {'fp16' if args.dtype == 'f16' else args.dtype}"),
+        "value": round(value, 2), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"dinov2-{args.model} (ViT-{args.model[0].upper()}/14, {args.registers} registers) "
