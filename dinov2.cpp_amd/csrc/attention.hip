@@ -157,6 +157,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
         stoff[j] = (unsigned)r * rowb + lc;
         stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
     }
+    // The V tile has its own chunk swizzle (see vaddr below): chunk ^ (((row >> 1) & 1) << 2) instead of K's
+    // chunk ^ ((row >> 1) & 7).  Both depend on the lane only (row >> 1 = 4 * (j * NWV + wid) + (lane >> 4)), and the chunk
+    // index is bits 6:4 of the source offset, so V's source offset is K's with those bits XORed by a per-lane constant.
+    const unsigned vswz = (unsigned)((((wid & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;
     auto stage = [&](int buf, int jt) {  // tiles are staged in order: jt only documents which one this call fetches
         char* sK = smem + buf * 2 * TILEB;
         char* sV = sK + TILEB;
@@ -165,7 +169,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
             const unsigned off = stoff[j] < stmax[j] ? stoff[j] : stmax[j];
             stoff[j] += KT * rowb;
             glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);  // uniform base + 32-bit lane offset: scalar-base loads
-            glds16(vbase + off, sV + (j * NWV + wid) * 8 * ROWB);
+            glds16(vbase + (off ^ vswz), sV + (j * NWV + wid) * 8 * ROWB);
         }
     };
 
@@ -176,7 +180,10 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
     for (int ks = 0; ks < 4; ++ks) kaddr[ks] = ql * ROWB + (((ks * 2 + hh) ^ sw) << 4);
     // V^T gather for ds_read_b64_tr_b16: within each 16-lane group, lane t supplies the address of
     // V[key0 + (t >> 2)][d0 + 4*(t & 3) .. +3] and receives V[key0 + 0..3][d0 + t].  key0 = 16t + 8*half + 4*hh: the row
-    // swizzle term ((row >> 1) & 7) does not depend on t, so four base offsets + t * 2048 as an immediate cover the tile.
+    // swizzle term does not depend on t, so four base offsets + t * 2048 as an immediate cover the tile.  The V tile's swizzle
+    // is chunk ^ (((row >> 1) & 1) << 2): the 32 lanes of one LDS cycle read 4 consecutive rows x 64 bytes, and this puts
+    // rows r, r+1, r+2, r+3 on the four 64-byte quarters of the 256-byte bank row (with K's swizzle rows r and r+2 shared
+    // banks: SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE, every V^T read took two passes).
     const int t16 = lane & 15;
     int vaddr[2][2];
 #pragma unroll
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(NWV * 64, NWV == 8 ? 4 : 2) void attention_kernel(c
         for (int db = 0; db < 2; ++db) {
             const int row0 = 8 * half + 4 * hh + (t16 >> 2);
             const int colbyte = db * 64 + (((lane >> 4) & 1) * 16 + (t16 & 3) * 4) * 2;
-            vaddr[half][db] = row0 * ROWB + ((((colbyte >> 4) ^ ((row0 >> 1) & 7)) << 4) | (colbyte & 15));
+            vaddr[half][db] = row0 * ROWB + ((((colbyte >> 4) ^ (((row0 >> 1) & 1) << 2)) << 4) | (colbyte & 15));
         }
 
     f32x16 o[2];
@@ -369,12 +376,13 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
         koff[j] = voff[j] = (unsigned)r * rowb + lc;
         stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
     }
+    const unsigned vswz = (unsigned)((((wid & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;  // as in attention_kernel
     auto stage_k1 = [&](int buf, int j) {
         glds16(kbase + (koff[j] < stmax[j] ? koff[j] : stmax[j]), smem + buf * 2 * TILEB + (j * 4 + wid) * 8 * ROWB);
         koff[j] += KT * rowb;
     };
     auto stage_v1 = [&](int buf, int j) {
-        glds16(kbase + (voff[j] < stmax[j] ? voff[j] : stmax[j]) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * 4 + wid) * 8 * ROWB);
+        glds16(kbase + ((voff[j] < stmax[j] ? voff[j] : stmax[j]) ^ vswz) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * 4 + wid) * 8 * ROWB);
         voff[j] += KT * rowb;
     };
     auto stage_k = [&](int buf) { stage_k1(buf, 0); stage_k1(buf, 1); };
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
         for (int db = 0; db < 2; ++db) {
             const int row0 = 8 * half + 4 * hh + (t16 >> 2);
             const int colbyte = db * 64 + (((lane >> 4) & 1) * 16 + (t16 & 3) * 4) * 2;
-            vaddr[half][db] = row0 * ROWB + ((((colbyte >> 4) ^ ((row0 >> 1) & 7)) << 4) | (colbyte & 15));
+            vaddr[half][db] = row0 * ROWB + ((((colbyte >> 4) ^ (((row0 >> 1) & 1) << 2)) << 4) | (colbyte & 15));
         }
     auto read_vt = [&](const char* sV, int t, int db) {
         vec8 vf;
