@@ -77,6 +77,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 
     // ---- staging: 4 + 4 global_load_lds_dwordx4 per thread per K-tile, rows clamped to M ----
     unsigned xsrc[4], wsrc[4];  // byte offsets from p.A / p.W (both far below 4 GiB)
+#if DINO_GEMM_DBG & 1024  // experiment: in K-loop iteration kt only the wave group (kt & 1) stages -- its rows AND its SIMD partner's
+    unsigned xsrc2[4], wsrc2[4];
+#endif
     const int srow = lane >> 3;
     auto set_tile = [&](int m0, int n0) {
 #if DINO_GEMM_DBG & 256  // timing experiment only: every tile stages tile (0,0) -> operands stay L2-resident
@@ -91,6 +94,16 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             gm = gm < M ? gm : M - 1;
             if (j < XREP) xsrc[j] = (unsigned)gm * (unsigned)(K * 2) + lc * 16;
             wsrc[j] = (unsigned)(n0 + row) * (unsigned)(K * 2) + lc * 16;
+#if DINO_GEMM_DBG & 1024
+            {
+                const int row2 = (j * NW + (wid ^ 4)) * 8 + srow;
+                const int lc2 = (lane & 7) ^ ((row2 >> 1) & 7);
+                int gm2 = m0 + row2;
+                gm2 = gm2 < M ? gm2 : M - 1;
+                if (j < XREP) xsrc2[j] = (unsigned)gm2 * (unsigned)(K * 2) + lc2 * 16;
+                wsrc2[j] = (unsigned)(n0 + row2) * (unsigned)(K * 2) + lc2 * 16;
+            }
+#endif
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -113,6 +126,14 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         glds16(src, dst);
     };
 
+#if DINO_GEMM_DBG & 1024
+    auto piece2 = [&](int buf, int kt, int j) {  // the same piece of the SIMD partner (wave wid ^ 4)
+        if (j < 4 && j >= XREP) return;
+        char* dst = smem + buf * STAGE + (j < 4 ? 0 : BM * ROWB) + ((j & 3) * NW + (wid ^ 4)) * 8 * ROWB;
+        const char* src = (j < 4 ? (const char*)p.A + xsrc2[j & 3] : (const char*)p.W + wsrc2[j & 3]) + (size_t)kt * (BK * 2);
+        glds16(src, dst);
+    };
+#endif
     const int wx = wid >> 2, ww = wid & 3;
     const int grp = wid >> 2;  // waves 0-3 / 4-7: the two waves that share each SIMD
     const int fr = lane & 31, fh = lane >> 5;
@@ -223,6 +244,11 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         __builtin_amdgcn_sched_barrier(0);         \
     }
     // slot helpers: piece ja for group 0 / piece jb for group 1 of K-tile KT into stage BUF when COND holds
+#if DINO_GEMM_DBG & 1024
+#define DINO_SLOT_A(COND, BUF, KT, JA) if ((COND) && own) { piece(BUF, KT, JA); piece2(BUF, KT, JA); }
+#define DINO_SLOT_B(COND, BUF, KT, JB)
+#define DINO_SLOT_AB(COND, BUF, KT, JA, JB) DINO_SLOT_A(COND, BUF, KT, JA)
+#else
 #define DINO_SLOT_A(COND, BUF, KT, JA) if ((COND) && grp == 0) piece(BUF, KT, JA)
 #define DINO_SLOT_B(COND, BUF, KT, JB) if ((COND) && grp == 1) piece(BUF, KT, JB)
 #define DINO_SLOT_AB(COND, BUF, KT, JA, JB) \
@@ -230,6 +256,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         if (grp == 0) piece(BUF, KT, JA);   \
         else piece(BUF, KT, JB);            \
     }
+#endif
 #define DINO_MFMAS(XF, WF) DINO_MFMAS_P(XF, WF, , , , )
 
         __syncthreads();  // K-tile 0 of this tile has landed (vmcnt(0) precedes the barrier; also drains the previous
@@ -242,6 +269,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = (unsigned)((kt + 1) & 1) * STAGE;
             const int nb = (kt + 1) & 1;
+#if DINO_GEMM_DBG & 1024
+            const bool own = (kt & 1) == grp;
+#endif
             const bool more = kt + 1 < nk;      // K-tile kt+1 exists: its pieces 0-2 were issued behind the last barrier,
                                                 // pieces 3-7 go out with the first two MFMA groups of this iteration
             DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
