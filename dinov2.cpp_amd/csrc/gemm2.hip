@@ -20,7 +20,8 @@
 #include "device_types.h"
 #include "kernels.h"
 
-// tuning aid, compile-time only (make variant): 2 = skip in-loop staging, 4 = skip MFMA
+// tuning aid, compile-time only (make variant): 2 = skip in-loop staging, 4 = skip MFMA;
+// 1024 = single-owner staging experiment (one wave group stages per K-loop iteration; measured slower, see profiles/r01_gemm_tuning.md)
 #ifndef DINO_GEMM_DBG
 #define DINO_GEMM_DBG 0
 #endif
