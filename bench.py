@@ -63,7 +63,24 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        # RCCL prints a version banner with printf -- to STDOUT, flushed when the process exits, i.e. after the JSON line this
+        # script owes the driver.  Point fd 1 at stderr while the communicator comes up, flush C stdio, then restore it, so
+        # that stdout carries the one JSON line and nothing else.
+        import ctypes
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.barrier()  # forces the communicator (and the banner) now
+            torch.cuda.synchronize()
+        finally:
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     cfg = pkg.synth.CONFIGS[args.model]
     num_classes = 1000
@@ -270,6 +287,11 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
     }
+    try:  # anything a native library still holds in C stdio goes out BEFORE the JSON line, which stays the last one
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
