@@ -114,6 +114,7 @@ def main():
     imgs = torch.randn((B, 3, S, S), generator=gen, device=f"cuda:{local}", dtype=torch.float32)
     logits = torch.empty((B, num_classes), device=f"cuda:{local}", dtype=torch.float32)
     probs = torch.empty_like(logits)
+    torch.cuda.synchronize()  # the inputs come from torch's stream; the session runs on its own non-blocking stream
 
     def step():
         sess.predict_device(imgs.data_ptr(), B, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=logits.data_ptr(),
@@ -208,6 +209,7 @@ def main():
     p50 = p99 = None
     if not args.no_latency:
         one = imgs[:1].contiguous()
+        torch.cuda.synchronize()
         lat = []
         for i in range(220):  # 20 warm-up + 200 timed forwards
             torch.cuda.synchronize()

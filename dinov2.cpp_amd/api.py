@@ -61,6 +61,11 @@ class Output(C.Structure):
                 ("topk_ids", C.c_void_p), ("topk_probs", C.c_void_p), ("topk", C.c_int32), ("on_device", C.c_int32)]
 
 
+class GroupOpts(C.Structure):
+    _fields_ = [("load", LoadOpts), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("broadcast", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
 _lib = None
 
 
@@ -102,6 +107,17 @@ def lib():
     L.dinov2_hip_session_stream.argtypes = [vp]
     L.dinov2_hip_session_stream.restype = vp
     L.dinov2_hip_predict.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, cp, sz]
+    L.dinov2_hip_default_group_opts.argtypes = [C.POINTER(GroupOpts)]
+    L.dinov2_hip_default_group_opts.restype = None
+    L.dinov2_hip_group_create.argtypes = [cp, C.POINTER(GroupOpts), C.POINTER(vp), cp, sz]
+    L.dinov2_hip_group_free.argtypes = [vp]
+    L.dinov2_hip_group_free.restype = None
+    L.dinov2_hip_group_size.argtypes = [vp]
+    L.dinov2_hip_group_model.argtypes = [vp, i32]
+    L.dinov2_hip_group_model.restype = vp
+    L.dinov2_hip_group_broadcast_ms.argtypes = [vp]
+    L.dinov2_hip_group_broadcast_ms.restype = C.c_double
+    L.dinov2_hip_group_predict.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, cp, sz]
     L.dinov2_hip_interpolate_pos_embed.argtypes = [vp, i32, i32, vp]
     L.dinov2_hip_preprocess_size.argtypes = [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.dinov2_hip_preprocess.argtypes = [i32, vp, i32, i32, i32, vp]
@@ -118,6 +134,7 @@ def lib():
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_pca_ritz.argtypes = [vp, vp, vp, i32, vp, vp]
     L.dinov2_hip_op_probe_tr16.argtypes = [C.POINTER(C.c_int16)]
+    L.dinov2_hip_op_preprocess_u8.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     L.dinov2_hip_op_gemm_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_gemm_bench.restype = C.c_float
     L.dinov2_hip_op_attention_bench.argtypes = [i32] * 6
@@ -217,6 +234,83 @@ class Model:
             pass
 
 
+def _alloc_outputs(hp, B, hh, ww, layout, classify, topk, want):
+    """Host output arrays + the filled Output struct for a predict of B images (shared by Session and Group)."""
+    Hd, R, ps = hp.hidden_size, hp.num_register_tokens, hp.patch_size
+    nh, nw = preprocess_size(1 if classify else 0, hh, ww, ps) if layout == U8_BGR_HWC else (hh, ww)
+    P = (nh // ps) * (nw // ps)
+    out = {}
+    o = Output()
+    if "cls" in want:
+        out["cls"] = np.empty((B, Hd), np.float32)
+        o.cls = out["cls"].ctypes.data
+    if "patch_tokens" in want:
+        out["patch_tokens"] = np.empty((B, P + (R if classify else 0), Hd), np.float32)
+        o.patch_tokens = out["patch_tokens"].ctypes.data
+    if classify:
+        Cn = hp.num_classes
+        if "logits" in want:
+            out["logits"] = np.empty((B, Cn), np.float32)
+            o.logits = out["logits"].ctypes.data
+        if "probs" in want:
+            out["probs"] = np.empty((B, Cn), np.float32)
+            o.probs = out["probs"].ctypes.data
+        if topk > 0:
+            out["topk_ids"] = np.empty((B, topk), np.int32)
+            out["topk_probs"] = np.empty((B, topk), np.float32)
+            o.topk_ids, o.topk_probs, o.topk = out["topk_ids"].ctypes.data, out["topk_probs"].ctypes.data, topk
+    return out, o
+
+
+class Group:
+    """dinov2_hip_group: N devices behind one handle -- one host thread + session per device inside the library, the global
+    batch split contiguously, outputs landing at the shard offsets of the caller's arrays."""
+
+    def __init__(self, path: str, devices=None, *, dtype: int = F16, classify: bool = True, broadcast: bool = True):
+        L = lib()
+        o = GroupOpts()
+        L.dinov2_hip_default_group_opts(C.byref(o))
+        o.load.compute_dtype, o.load.classify = dtype, int(classify)
+        o.broadcast = int(broadcast)
+        if devices is not None:
+            self._devs = (C.c_int32 * len(devices))(*devices)
+            o.n_devices, o.devices = len(devices), self._devs
+        h = C.c_void_p()
+        err = _errbuf()
+        rc = L.dinov2_hip_group_create(path.encode(), C.byref(o), C.byref(h), err, len(err))
+        if rc != 0:
+            raise DinoError(rc, err.value.decode(errors="replace"))
+        self._h = h
+        self.size = int(L.dinov2_hip_group_size(h))
+        self.hparams = HParams()
+        L.dinov2_hip_model_hparams(L.dinov2_hip_group_model(h, 0), C.byref(self.hparams))
+        self.broadcast_ms = float(L.dinov2_hip_group_broadcast_ms(h))
+
+    def predict(self, images: np.ndarray, *, classify: bool = False, layout: int = RGB_CHW, topk: int = 0,
+                want=("cls", "patch_tokens", "logits", "probs")) -> dict:
+        img = np.ascontiguousarray(images, dtype=np.uint8 if layout == U8_BGR_HWC else np.float32)
+        B = img.shape[0]
+        hh, ww = (img.shape[2], img.shape[3]) if layout == RGB_CHW else (img.shape[1], img.shape[2])
+        out, o = _alloc_outputs(self.hparams, B, hh, ww, layout, classify, topk, want)
+        i = Input(img.ctypes.data, B, hh, ww, layout, 0)
+        err = _errbuf()
+        rc = lib().dinov2_hip_group_predict(self._h, C.byref(i), C.byref(o), CLASSIFY if classify else 0, err, len(err))
+        if rc != 0:
+            raise DinoError(rc, err.value.decode(errors="replace"))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().dinov2_hip_group_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Session:
     """ggml_gallocr_t counterpart: stream + workspace, reusable across predicts."""
 
@@ -238,30 +332,7 @@ class Session:
             img = img[None]
         B = img.shape[0]
         hh, ww = (img.shape[2], img.shape[3]) if layout == RGB_CHW else (img.shape[1], img.shape[2])
-        hp = self.model.hparams
-        Hd, R, ps = hp.hidden_size, hp.num_register_tokens, hp.patch_size
-        nh, nw = preprocess_size(1 if classify else 0, hh, ww, ps) if layout == U8_BGR_HWC else (hh, ww)
-        P = (nh // ps) * (nw // ps)
-        out = {}
-        o = Output()
-        if "cls" in want:
-            out["cls"] = np.empty((B, Hd), np.float32)
-            o.cls = out["cls"].ctypes.data
-        if "patch_tokens" in want:
-            out["patch_tokens"] = np.empty((B, P + (R if classify else 0), Hd), np.float32)
-            o.patch_tokens = out["patch_tokens"].ctypes.data
-        if classify:
-            Cn = hp.num_classes
-            if "logits" in want:
-                out["logits"] = np.empty((B, Cn), np.float32)
-                o.logits = out["logits"].ctypes.data
-            if "probs" in want:
-                out["probs"] = np.empty((B, Cn), np.float32)
-                o.probs = out["probs"].ctypes.data
-            if topk > 0:
-                out["topk_ids"] = np.empty((B, topk), np.int32)
-                out["topk_probs"] = np.empty((B, topk), np.float32)
-                o.topk_ids, o.topk_probs, o.topk = out["topk_ids"].ctypes.data, out["topk_probs"].ctypes.data, topk
+        out, o = _alloc_outputs(self.model.hparams, B, hh, ww, layout, classify, topk, want)
         i = Input(img.ctypes.data, B, hh, ww, layout, 0)
         err = _errbuf()
         rc = lib().dinov2_hip_predict(self._h, C.byref(i), C.byref(o), CLASSIFY if classify else 0, err, len(err))

@@ -48,6 +48,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, N = p.N, K = p.K;
+    const size_t lda = p.lda ? p.lda : K, ldw = p.ldw ? p.ldw : K;
 
     const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
     const int lid = xcd_remap(blockIdx.x, ntn * ntm);
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        asrc[j] = (const char*)p.A + ((size_t)gm * K) * 2 + lc * 16;
+        asrc[j] = (const char*)p.A + ((size_t)gm * lda) * 2 + lc * 16;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row;
         gn = gn < N ? gn : N - 1;
-        bsrc[j] = (const char*)p.W + ((size_t)gn * K) * 2 + lc * 16;
+        bsrc[j] = (const char*)p.W + ((size_t)gn * ldw) * 2 + lc * 16;
     }
 
     auto stage = [&](int buf, int kt) {
@@ -297,7 +298,8 @@ hipError_t gemm_init() {
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
-    if ((size_t)a.M * a.K * 2 >= ((size_t)1 << 32) || (size_t)a.N * a.K * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
+    const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
+    if ((size_t)a.M * lda_ * 2 >= ((size_t)1 << 32) || (size_t)a.N * ldw_ * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     static const int forced = [] {
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");
         return e ? atoi(e) : 0;
@@ -331,7 +333,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
             const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
             a1.M = M1;
             a2.M = a.M - M1;
-            a2.A = (const char*)a.A + (size_t)M1 * a.K * 2;
+            a2.A = (const char*)a.A + (size_t)M1 * lda_ * 2;
             a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
             const long tail192 = (long)ntn * ((a2.M + 191) / 192);
             const double costC = (double)R + rnd(tail192) * 0.79;

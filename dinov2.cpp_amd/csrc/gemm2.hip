@@ -54,6 +54,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, N = p.N, K = p.K;
+    const unsigned lda2 = (unsigned)(p.lda ? p.lda : K) * 2u, ldw2 = (unsigned)(p.ldw ? p.ldw : K) * 2u;  // row strides in bytes
     const int ntn = N / BN, ntm = (M + BM - 1) / BM;
     const int ntiles = ntn * ntm;
     // Block b sits on XCD b % 8 (observed placement; affects speed only): each XCD walks a contiguous chunk of the tile
@@ -90,19 +91,23 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = (j * NW + wid) * 8 + srow;
+#if DINO_GEMM_DBG & 32768  // timing experiment only (wrong results): un-swizzled source, lanes 0-7 of a row read its 128 B in order
+            const int lc = lane & 7;
+#else
             const int lc = (lane & 7) ^ ((row >> 1) & 7);
+#endif
             int gm = m0 + row;
             gm = gm < M ? gm : M - 1;
-            if (j < XREP) xsrc[j] = (unsigned)gm * (unsigned)(K * 2) + lc * 16;
-            wsrc[j] = (unsigned)(n0 + row) * (unsigned)(K * 2) + lc * 16;
+            if (j < XREP) xsrc[j] = (unsigned)gm * lda2 + lc * 16;
+            wsrc[j] = (unsigned)(n0 + row) * ldw2 + lc * 16;
 #if DINO_GEMM_DBG & 1024
             {
                 const int row2 = (j * NW + (wid ^ 4)) * 8 + srow;
                 const int lc2 = (lane & 7) ^ ((row2 >> 1) & 7);
                 int gm2 = m0 + row2;
                 gm2 = gm2 < M ? gm2 : M - 1;
-                if (j < XREP) xsrc2[j] = (unsigned)gm2 * (unsigned)(K * 2) + lc2 * 16;
-                wsrc2[j] = (unsigned)(n0 + row2) * (unsigned)(K * 2) + lc2 * 16;
+                if (j < XREP) xsrc2[j] = (unsigned)gm2 * lda2 + lc2 * 16;
+                wsrc2[j] = (unsigned)(n0 + row2) * ldw2 + lc2 * 16;
             }
 #endif
         }
@@ -181,13 +186,17 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
         u32x4 xf0[4], wf0[WREP], xf1[4], wf1[WREP];
+#if DINO_GEMM_DBG & 2048  // timing experiment only: no fragment ds_reads (MFMAs run on whatever these registers hold)
+        for (int i = 0; i < 4; ++i) xf0[i] = xf1[i] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        for (int i = 0; i < WREP; ++i) wf0[i] = wf1[i] = u32x4{(unsigned)tid, 5u, 6u, 7u};
+#endif
 
         // ---- main loop ---------------------------------------------------------------------------------------------
         // Rules followed for the inline-asm reads (cdna_hip_programming.md 5.7): every asm read is waited for by an asm
         // s_waitcnt before its first consumer, and a sched_barrier(0) follows each wait so no MFMA is hoisted above it.
 #define DINO_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define DINO_LOAD_FRAGS(XF, WF, BUFOFF, KS)                                      \
-    {                                                                            \
+    if (!(DINO_GEMM_DBG & 2048)) {                                               \
         const unsigned xa__ = xaddr[KS] + (BUFOFF), wa__ = waddr[KS] + (BUFOFF); \
         DINO_DSR(XF[0], xa__, 0);                                                \
         DINO_DSR(XF[1], xa__, 4096);                                             \
@@ -205,8 +214,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 #else
 #define DINO_PRIO(P)
 #endif
+#if DINO_GEMM_DBG & 4  // timing experiment only: no MFMA (one VALU op keeps the fragment registers and the accumulator live)
+#define DINO_MFMA1(XF, WF, I, J) \
+    acc[J][I][0] += __builtin_bit_cast(float, WF[J][0]) * __builtin_bit_cast(float, XF[I][0]);
+#else
 #define DINO_MFMA1(XF, WF, I, J) \
     acc[J][I] = E::mfma32(__builtin_bit_cast(vec8, WF[J]), __builtin_bit_cast(vec8, XF[I]), acc[J][I]);
+#endif
     // Eight MFMAs of one k-step with staging instructions in four slots: S0 before the 1st MFMA, S1 after the 3rd, S2
     // after the 6th, S3 after the 8th.  A global_load_lds occupies its wave's issue port for ~60-185 cycles, so wave
     // group 0 (waves 0-3) stages in S0,S1,S2 and group 1 (waves 4-7, their SIMD partners) in S1,S2,S3: the two waves of a
@@ -290,7 +304,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
             // of K-tile kt+1 has landed; after the barrier everyone's has.
             DINO_WAIT_LGKM(0);
-#if DINO_GEMM_DBG & 64  // timing experiment only: no barrier at all
+#if DINO_GEMM_DBG & 8192  // timing experiment only (wrong results): the newest 8 pieces stay in flight across the barrier
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#elif DINO_GEMM_DBG & 16384  // timing experiment only (wrong results): 16 pieces (two K-tiles) stay in flight
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#elif DINO_GEMM_DBG & 64  // timing experiment only: no barrier at all
 #elif DINO_GEMM_DBG & 16  // timing experiment only (wrong results): barrier WITHOUT waiting for the in-flight K-tile
             __builtin_amdgcn_s_barrier();
 #else

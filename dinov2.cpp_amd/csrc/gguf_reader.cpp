@@ -159,7 +159,15 @@ bool GgufFile::open(const std::string& path, std::string* err) {
     }
     uint64_t align = 32;
     if (const GgufValue* a = find("general.alignment")) align = a->u ? a->u : 32;
+    if (align > ((uint64_t)1 << 30)) {
+        *err = "implausible general.alignment";
+        return false;
+    }
     const uint64_t data0 = ((uint64_t)(c.p - base) + align - 1) / align * align;
+    if (data0 > map_len_ && !tensors_.empty()) {
+        *err = "GGUF data section starts past the end of the file";
+        return false;
+    }
     for (size_t i = 0; i < tensors_.size(); ++i) {
         auto& t = tensors_[i];
         uint32_t be, bb;
@@ -172,8 +180,13 @@ bool GgufFile::open(const std::string& path, std::string* err) {
             *err = "tensor '" + t.name + "' row length is not a multiple of its block size";
             return false;
         }
+        if (n == UINT64_MAX || n / be > UINT64_MAX / bb) {
+            *err = "tensor '" + t.name + "' has an implausible element count";
+            return false;
+        }
         t.nbytes = n / be * bb;
-        if (data0 + t.offset + t.nbytes > map_len_) {
+        // overflow-safe form of data0 + offset + nbytes <= map_len_ (a crafted offset near 2^64 wrapped the plain sum)
+        if (t.offset > map_len_ - data0 || t.nbytes > map_len_ - data0 - t.offset) {
             *err = "tensor '" + t.name + "' extends past the end of the file";
             return false;
         }

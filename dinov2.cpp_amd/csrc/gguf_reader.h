@@ -24,9 +24,13 @@ struct GgufTensor {
     uint64_t offset = 0;       // from the start of the data section
     uint64_t nbytes = 0;
     const uint8_t* data = nullptr;  // into the mapping
+    // product of the dimensions; UINT64_MAX when it does not fit (a crafted file): callers treat that as "too large"
     uint64_t nelements() const {
         uint64_t n = 1;
-        for (auto v : ne) n *= v;
+        for (auto v : ne) {
+            if (v != 0 && n > UINT64_MAX / v) return UINT64_MAX;
+            n *= v;
+        }
         return n;
     }
 };

@@ -26,6 +26,7 @@ struct GemmArgs {
     void* out;
     const float* aux;   // EPI_PATCH: pos [1+P, N]; EPI_RESID: layer-scale lambda [N]
     int M, N, K;
+    int lda, ldw;       // row strides of A and W in elements; 0 = K (dense)
     int ldo;            // leading dimension of out in elements
     int P, T, R;        // EPI_PATCH token mapping
     int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale

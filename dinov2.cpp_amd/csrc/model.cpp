@@ -340,6 +340,16 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
     HIP_TRY(gemm_init());
     m->arena_bytes = plan.total;
     HIP_TRY(hipMalloc((void**)&m->arena, plan.total));
+    // every early return below (HIP_TRY included) must give the arena back: the model struct has no destructor of its own
+    struct ArenaGuard {
+        dinov2_hip_model* m;
+        ~ArenaGuard() {
+            if (m && m->arena) {
+                (void)hipFree(m->arena);
+                m->arena = nullptr;
+            }
+        }
+    } arena_guard{m.get()};
     for (auto& it : plan.items) *it.slot = m->arena + it.offset;
 
     // host copy of the position embeddings for per-resolution interpolation
@@ -375,11 +385,9 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
             }
         }
         (void)hipFree(staging);
-        if (rc != DINOV2_HIP_OK) {
-            (void)hipFree(m->arena);
-            return rc;
-        }
+        if (rc != DINOV2_HIP_OK) return rc;
     }
+    arena_guard.m = nullptr;  // success: the arena now belongs to the model (dinov2_hip_model_free)
     *out = m.release();
     return DINOV2_HIP_OK;
 }
@@ -964,6 +972,10 @@ extern "C" int dinov2_hip_debug_hidden(dinov2_hip_session* s, const dinov2_hip_i
     const dinov2_hip_model* m = s->model;
     if (!out || layer < 0 || layer > (int)m->hp.num_hidden_layers) {
         set_err(err, errlen, "layer out of range");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    if (in->layout == DINOV2_HIP_U8_BGR_HWC) {  // check_input accepts raw images of any size; this entry point has no preprocess step
+        set_err(err, errlen, "debug_hidden takes preprocessed f32 images (BGR_HWC or RGB_CHW), not raw 8-bit input");
         return DINOV2_HIP_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m->device));

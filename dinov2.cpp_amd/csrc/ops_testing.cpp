@@ -185,18 +185,22 @@ extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32
     const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
     if (gemm_init() != hipSuccess) return -1.f;
     DevBuf dA, dW, dB, dX, dO;
-    if (dA.alloc((size_t)M * K * 2) != hipSuccess || dW.alloc((size_t)N * K * 2) != hipSuccess ||
+    // tuning aid: DINOV2_BENCH_PAD_A / _W = extra elements per row of A / W (row strides K + pad instead of the dense K)
+    const int padA = getenv("DINOV2_BENCH_PAD_A") ? atoi(getenv("DINOV2_BENCH_PAD_A")) : 0;
+    const int padW = getenv("DINOV2_BENCH_PAD_W") ? atoi(getenv("DINOV2_BENCH_PAD_W")) : 0;
+    if (dA.alloc((size_t)M * (K + padA) * 2) != hipSuccess || dW.alloc((size_t)N * (K + padW) * 2) != hipSuccess ||
         dB.alloc((size_t)N * 4) != hipSuccess || dX.alloc((size_t)std::max(N, 4096) * 4 * 2) != hipSuccess ||
         dO.alloc((size_t)M * N * 4) != hipSuccess)
         return -1.f;
-    fill_random_t(dt, dA.p, (size_t)M * K, 1, 1.0f);
-    fill_random_t(dt, dW.p, (size_t)N * K, 2, 0.05f);
+    fill_random_t(dt, dA.p, (size_t)M * (K + padA), 1, 1.0f);
+    fill_random_t(dt, dW.p, (size_t)N * (K + padW), 2, 0.05f);
     (void)hipMemset(dB.p, 0, (size_t)N * 4);
     (void)hipMemset(dX.p, 0, (size_t)std::max(N, 4096) * 8);
     (void)hipMemset(dO.p, 0, (size_t)M * N * 4);
     GemmArgs a{};
     a.A = dA.p; a.W = dW.p; a.bias = (const float*)dB.p; a.out = dO.p; a.aux = (const float*)dX.p;
     a.M = M; a.N = N; a.K = K; a.ldo = epilogue == EPI_SWIGLU ? N / 2 : N; a.P = 1; a.T = 2; a.R = 0;
+    a.lda = K + padA; a.ldw = K + padW;
     a.qcols = N / 3; a.qscale = 0.125f;
     if (epilogue == EPI_PATCH) { a.P = M; a.T = M + 1; }
     hipEvent_t e0, e1;
@@ -263,4 +267,23 @@ extern "C" int dinov2_hip_op_pca_ritz(const double* yprev, const double* ynext, 
     if (!yprev || !ynext || !gram || !evals || H < 8) return DINOV2_HIP_ERR_INVALID;
     dinov2::pca_ritz(yprev, ynext, gram, 1, H, evals, comp);
     return DINOV2_HIP_OK;
+}
+
+// preprocess_u8_kernel alone (mode 0 = dino_preprocess, 1 = dino_classify_preprocess): raw BGR bytes [B, h, w, 3] in, the
+// normalised f32 BGR image [B, oh, ow, 3] the forward would consume out -- so the kernel can be compared with
+// oracle/preprocess_np.py directly instead of through a whole forward.
+extern "C" int dinov2_hip_op_preprocess_u8(int32_t mode, const uint8_t* bgr, int32_t B, int32_t h, int32_t w, int32_t patch,
+                                           float* out) {
+    int32_t oh = 0, ow = 0;
+    if (!bgr || !out || B <= 0 || dinov2_hip_preprocess_size(mode, h, w, patch, &oh, &ow) != DINOV2_HIP_OK) return -1;
+    DevBuf dS, dD;
+    const size_t nsrc = (size_t)B * h * w * 3, ndst = (size_t)B * oh * ow * 3;
+    OP_TRY(dS.alloc(nsrc));
+    OP_TRY(dD.alloc(ndst * sizeof(float)));
+    OP_TRY(hipMemcpy(dS.p, bgr, nsrc, hipMemcpyHostToDevice));
+    const int rh = mode == 1 ? 256 : oh, rw = mode == 1 ? 256 : ow;
+    OP_TRY(launch_preprocess_u8((const uint8_t*)dS.p, (float*)dD.p, B, h, w, rh, rw, (rh - oh) / 2, (rw - ow) / 2, oh, ow, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(hipMemcpy(out, dD.p, ndst * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
 }

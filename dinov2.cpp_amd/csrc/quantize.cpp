@@ -185,8 +185,9 @@ extern "C" int dinov2_hip_quantize(const char* fname_inp, const char* fname_out,
         t.off = r.get<uint64_t>();
         tis.push_back(std::move(t));
     }
-    if (!r.ok || align == 0) { fail(err, errlen, "truncated or corrupt GGUF metadata"); return DINOV2_HIP_ERR_FORMAT; }
+    if (!r.ok || align == 0 || align > (1u << 20)) { fail(err, errlen, "truncated or corrupt GGUF metadata"); return DINOV2_HIP_ERR_FORMAT; }
     const size_t data0 = (r.p + align - 1) / align * align;
+    if (data0 > buf.size() && !tis.empty()) { fail(err, errlen, "GGUF data section starts past the end of the file"); return DINOV2_HIP_ERR_FORMAT; }
 
     // ---- re-encode ----
     std::vector<std::vector<uint8_t>> datas(tis.size());
@@ -195,7 +196,12 @@ extern "C" int dinov2_hip_quantize(const char* fname_inp, const char* fname_out,
     for (size_t i = 0; i < tis.size(); ++i) {
         const TI& t = tis[i];
         uint64_t n = 1;
-        for (auto v : t.ne) n *= v;
+        bool huge = false;
+        for (auto v : t.ne) {
+            if (v != 0 && n > (UINT64_MAX / 8) / v) huge = true;  // n * (bytes per element <= 4) must not wrap either
+            else n *= v;
+        }
+        if (huge) { fail(err, errlen, "implausible element count: ", t.name); return DINOV2_HIP_ERR_FORMAT; }
         const size_t esz = t.type == 0 ? 4 : t.type == 1 ? 2 : 0;
         size_t nd = t.ne.size();
         while (nd > 1 && t.ne[nd - 1] == 1) --nd;
@@ -205,7 +211,8 @@ extern "C" int dinov2_hip_quantize(const char* fname_inp, const char* fname_out,
         if (esz) nbytes = (size_t)n * esz;
         else if (block_bytes((int)t.type)) nbytes = (size_t)n / QK * block_bytes((int)t.type);
         else { fail(err, errlen, "unsupported tensor type for ", t.name); return DINOV2_HIP_ERR_UNSUPPORTED; }
-        if (data0 + t.off + nbytes > buf.size()) { fail(err, errlen, "tensor data out of bounds: ", t.name); return DINOV2_HIP_ERR_FORMAT; }
+        // overflow-safe form of data0 + off + nbytes <= size (a crafted offset near 2^64 wrapped the plain sum)
+        if (t.off > buf.size() - data0 || nbytes > buf.size() - data0 - t.off) { fail(err, errlen, "tensor data out of bounds: ", t.name); return DINOV2_HIP_ERR_FORMAT; }
         const uint8_t* src = &buf[data0 + t.off];
         total_in += (double)nbytes;
         if (quant) {
@@ -229,12 +236,13 @@ extern "C" int dinov2_hip_quantize(const char* fname_inp, const char* fname_out,
         total_out += (double)datas[i].size();
     }
 
-    // ---- write (general.architecture first, the other KVs in file order, `ftype` replaced; 32-byte aligned tensors) ----
+    // ---- write (general.architecture first, the other KVs in file order, `ftype` replaced; tensors aligned to the INPUT's
+    //      general.alignment, whose KV is copied through unchanged -- writing 32 regardless corrupted files with another value) ----
     std::vector<uint8_t> out;
     const uint32_t v3 = 3;
     uint64_t nkv_out = 1;
     for (const KV& kv : kvs) nkv_out += kv.key != "general.architecture";
-    const uint64_t nt = tis.size(), a = 32;
+    const uint64_t nt = tis.size(), a = align;
     put(out, "GGUF", 4);
     put(out, &v3, 4);
     put(out, &nt, 8);

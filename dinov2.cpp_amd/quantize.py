@@ -79,7 +79,9 @@ def dino_model_quantize(fname_inp: str, fname_out: str, itype: int) -> bool:
         print(f"dino_model_quantize: invalid quantization type {itype}", file=sys.stderr)  # dinov2.cpp:365-373
         return False
     _, kvs, tensors = _read(fname_inp)
-    w = gw.GGUFWriter(arch=next((v for k, t, v in kvs if k == "general.architecture"), "dinov2"))
+    # the output keeps the input's general.alignment (the KV is copied through below): tensors must be laid out with it
+    w = gw.GGUFWriter(arch=next((v for k, t, v in kvs if k == "general.architecture"), "dinov2"),
+                      alignment=int(next((v for k, t, v in kvs if k == "general.alignment"), gw.DEFAULT_ALIGNMENT)))
     for k, t, v in kvs:
         if k == "general.architecture":
             continue

@@ -35,12 +35,14 @@ def flops_per_image(cfg: dict, height: int, width: int, registers: int, num_clas
 
 
 def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: int = 4, num_classes: int = 1000,
-                         seed: int = 42, wtype: str = "f16", layers: int | None = None) -> dict:
+                         seed: int = 42, wtype: str = "f16", layers: int | None = None, head_std: float = 0.02) -> dict:
     """Write a seeded random DINOv2 GGUF.  Returns the hparams dict.
 
     wtype: storage type of the 2-D `*.weight` matrices ("f16", "f32", "q4_0", "q4_1", "q5_0", "q5_1",
     "q8_0"), mirroring what /root/reference/quantize.cpp produces (conv kernel and 1-D tensors keep
     their dtypes, dinov2.cpp:227-236).
+    head_std: standard deviation of the classifier weights.  0.02 gives max|logit| ~ 2-3 over 1000 classes; trained
+    ImageNet heads produce |logit| of 10-20, which 0.12 reproduces (used by the absolute-error parity test).
     """
     cfg = dict(CONFIGS[model]) if isinstance(model, str) else dict(model)
     if layers is not None:
@@ -112,7 +114,7 @@ def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: i
     vec("layernorm.weight", (H,), 0.1, 1.0)
     vec("layernorm.bias", (H,), 0.05)
     if num_classes > 0:
-        mat("classifier.weight", (num_classes, 2 * H), 0.02)
+        mat("classifier.weight", (num_classes, 2 * H), head_std)
         vec("classifier.bias", (num_classes,), 0.05)
     w.write(path)
     return dict(cfg, registers=registers, num_classes=num_classes, wtype=wtype)

@@ -23,8 +23,16 @@
 //   print_usage / dino_params_parse  dinov2.h:114-116             same
 //   dino_model_quantize           dinov2.h:118                    same
 //
-// `Mat32f` is layout-compatible with a continuous CV_32FC3 cv::Mat; define DINOV2_WITH_OPENCV before including to
-// get cv::Mat / cv::Size overloads.
+// `Mat32f` is layout-compatible with a continuous CV_32FC3 cv::Mat.
+//
+// Define DINOV2_WITH_OPENCV before including to get the reference's OpenCV-typed surface on top (dinov2.h:85-112):
+// dino_output::patch_tokens becomes a cv::Mat (fed to cv::PCA at inference.cpp:77-78), and dino_preprocess /
+// dino_classify_preprocess / dino_model_load / dino_predict take cv::Mat / cv::Size exactly as dinov2.h:93-112 declare them.
+// Define DINOV2_COMPAT_GGML_NAMES as well to get the handful of ggml identifiers the reference's mains touch around the two
+// calls (ggml_time_init/ms, ggml_backend_synchronize(model.backend), ggml_gallocr_new/free, the three frees of
+// inference.cpp:70-73), so that inference.cpp / realtime.cpp compile with only their #include lines changed.
+// This image has no OpenCV: the branch is compile-checked against a minimal stand-in of the few cv:: types it touches
+// (tests/cpp/opencv_stub/, test infrastructure) and has never been built against the real library.
 #pragma once
 #include <algorithm>
 #include <cstdint>
@@ -41,6 +49,9 @@
 
 #ifdef DINOV2_WITH_OPENCV
 #include <opencv2/core/mat.hpp>
+#endif
+#ifdef DINOV2_COMPAT_GGML_NAMES
+#include <chrono>
 #endif
 
 struct Size2i {
@@ -84,10 +95,18 @@ struct dino_params {  // dinov2.h:57-68
     int compute_dtype = DINOV2_HIP_F16;   // extension: DINOV2_HIP_F16 | DINOV2_HIP_BF16
 };
 
+struct dino_model;
+// what `model.backend` / `model.ctx` / `model.buffer` (dinov2.h:50-53) are here: tokens that lead back to the model, so the
+// reference's calls on them (DINOV2_COMPAT_GGML_NAMES below) have something to work on
+struct dinov2_compat_backend { dino_model* model = nullptr; };
+struct dinov2_compat_ctx { dino_model* model = nullptr; };
+
 struct dino_model {  // dinov2.h:49-55 (ctx/backend/buffer/tensors collapse into one opaque handle)
     dino_hparams hparams;
     dinov2_hip_model* handle = nullptr;
     dinov2_hip_session* default_session = nullptr;
+    dinov2_compat_backend backend{this};  // dinov2.h:50
+    dinov2_compat_ctx ctx{this}, buffer{this};  // dinov2.h:51-52
     dino_model() = default;
     dino_model(const dino_model&) = delete;
     dino_model& operator=(const dino_model&) = delete;
@@ -97,10 +116,16 @@ struct dino_model {  // dinov2.h:49-55 (ctx/backend/buffer/tensors collapse into
     }
 };
 
+#ifdef DINOV2_WITH_OPENCV
+using dino_mat = cv::Mat;  // dinov2.h:87: std::optional<cv::Mat> patch_tokens
+#else
+using dino_mat = Mat32f;
+#endif
+
 struct dino_output {  // dinov2.h:85-88
     std::optional<std::vector<uint32_t>> preds;  // top-k class ids (the reference stores uint32(prob): dinov2.cpp:975)
     std::optional<std::vector<float>> probs;     // their probabilities (extension)
-    std::optional<Mat32f> patch_tokens;          // P x H, row = y*w0 + x (dinov2.cpp:979-992)
+    std::optional<dino_mat> patch_tokens;        // P x H CV_32F, row = y*w0 + x, owning (dinov2.cpp:979-992)
 };
 
 // dinov2.h:98-99 / dinov2.cpp:239-352.  img_size is unused, exactly as in the reference.
@@ -131,6 +156,7 @@ inline bool dino_model_load(Size2i /*img_size*/, const std::string& fname, dino_
     printf("%s: patch_size             = %u\n", __func__, h.patch_size);
     printf("%s: img_size               = %u\n", __func__, h.img_size);
     printf("%s: ftype                  = %u\n", __func__, h.ftype);
+    printf("%s: qntvr                  = %u\n", __func__, h.ftype / 1000u);  // GGML_QNT_VERSION_FACTOR (dinov2.cpp:286,295)
     if (params.classify && hp.has_classifier) {
         printf("%s: num_classes            = %u\n", __func__, h.num_classes);
         for (uint32_t i = 0; i < h.num_classes; ++i) {
@@ -178,11 +204,16 @@ inline std::unique_ptr<dino_output> dino_predict(const dino_model& model, const 
     } else {
         const int ps = (int)model.hparams.patch_size;
         const int P = (img.rows / ps) * (img.cols / ps), H = (int)model.hparams.hidden_size;
+#ifdef DINOV2_WITH_OPENCV
+        cv::Mat m(P, H, CV_32F);  // owning, continuous: what dinov2.cpp:979-992 returns
+        out.patch_tokens = reinterpret_cast<float*>(m.data);
+#else
         Mat32f m;
         m.rows = P; m.cols = H; m.channels = 1;
         m.owner = std::make_shared<std::vector<float>>((size_t)P * H);
         m.data = m.owner->data();
         out.patch_tokens = m.data;
+#endif
         if (dinov2_hip_predict(s, &in, &out, 0, err, sizeof err) != DINOV2_HIP_OK) {
             fprintf(stderr, "%s: %s\n", __func__, err);
             return {};
@@ -278,14 +309,73 @@ inline bool dino_model_quantize(const std::string& fname_inp, const std::string&
 }
 
 #ifdef DINOV2_WITH_OPENCV
+// ---- the reference's OpenCV-typed declarations (dinov2.h:93-112), as thin adapters over the functions above ----
 inline bool dino_model_load(cv::Size sz, const std::string& fname, dino_model& model, const dino_params& params) {
     return dino_model_load(Size2i{sz.width, sz.height}, fname, model, params);
 }
 inline std::unique_ptr<dino_output> dino_predict(const dino_model& model, const cv::Mat& img, const dino_params& params,
                                                  dinov2_hip_session* allocr = nullptr) {
+    if (img.type() != CV_32FC3) {
+        fprintf(stderr, "%s: need a CV_32FC3 image (dino_preprocess output)\n", __func__);
+        return {};
+    }
     cv::Mat c = img.isContinuous() ? img : img.clone();
     Mat32f v;
-    v.rows = c.rows; v.cols = c.cols; v.channels = c.channels(); v.data = (float*)c.data;
+    v.rows = c.rows; v.cols = c.cols; v.channels = 3; v.data = reinterpret_cast<float*>(c.data);
     return dino_predict(model, v, params, allocr);
 }
-#endif
+namespace dinov2_compat_detail {
+inline cv::Mat preprocess_cv(int mode, cv::Mat& img, const dino_hparams& hp) {
+    cv::Mat out;
+    if (img.empty() || img.type() != CV_8UC3) {
+        fprintf(stderr, "dino_preprocess: need a CV_8UC3 image (cv::imread(..., cv::IMREAD_COLOR))\n");
+        return out;
+    }
+    cv::Mat c = img.isContinuous() ? img : img.clone();
+    int32_t oh = 0, ow = 0;
+    if (dinov2_hip_preprocess_size(mode, c.rows, c.cols, (int32_t)hp.patch_size, &oh, &ow) != DINOV2_HIP_OK) return out;
+    out.create(oh, ow, CV_32FC3);
+    if (dinov2_hip_preprocess(mode, c.data, c.rows, c.cols, (int32_t)hp.patch_size, reinterpret_cast<float*>(out.data)) != DINOV2_HIP_OK)
+        out.release();
+    return out;
+}
+}  // namespace dinov2_compat_detail
+// dinov2.h:94, 96 (non-const reference and unused img_size, as declared there)
+inline cv::Mat dino_classify_preprocess(cv::Mat& img, cv::Size /*img_size*/, const dino_hparams& params) {
+    return dinov2_compat_detail::preprocess_cv(1, img, params);
+}
+inline cv::Mat dino_preprocess(cv::Mat& img, cv::Size /*img_size*/, const dino_hparams& params) {
+    return dinov2_compat_detail::preprocess_cv(0, img, params);
+}
+#endif  // DINOV2_WITH_OPENCV
+
+#ifdef DINOV2_COMPAT_GGML_NAMES
+// ---- the ggml identifiers the reference's mains use AROUND dino_model_load / dino_predict (inference.cpp:25,60-73;
+// realtime.cpp:56,62,68-72), mapped onto the C-ABI so those files need no edits beyond their #include lines.  Nothing here
+// is ggml: `ggml_gallocr_t` is the session handle that plays the allocator's role. ----
+using ggml_gallocr_t = dinov2_hip_session*;
+struct dinov2_compat_buft { dino_model* model; };
+inline void ggml_time_init() {}
+inline int64_t ggml_time_ms() {
+    return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline void ggml_backend_synchronize(const dinov2_compat_backend& b) {  // inference.cpp:61,66: the timed region's fences
+    if (b.model && b.model->default_session) dinov2_hip_session_sync(b.model->default_session);
+}
+inline dinov2_compat_buft ggml_backend_get_default_buffer_type(const dinov2_compat_backend& b) { return {b.model}; }
+inline ggml_gallocr_t ggml_gallocr_new(dinov2_compat_buft t) {  // inference.cpp:62: a reusable session (stream + workspace)
+    dinov2_hip_session* s = nullptr;
+    char err[256] = {0};
+    if (!t.model || dinov2_hip_session_create(t.model->handle, nullptr, &s, err, sizeof err) != DINOV2_HIP_OK)
+        fprintf(stderr, "%s: %s\n", __func__, err);
+    return s;
+}
+inline void ggml_gallocr_free(ggml_gallocr_t a) { dinov2_hip_session_free(a); }          // inference.cpp:71
+inline void ggml_free(dinov2_compat_ctx&) {}                                             // inference.cpp:70: owned by dino_model
+inline void ggml_backend_buffer_free(dinov2_compat_ctx& b) {                             // inference.cpp:72: the weight arena
+    if (!b.model) return;
+    if (b.model->default_session) { dinov2_hip_session_free(b.model->default_session); b.model->default_session = nullptr; }
+    if (b.model->handle) { dinov2_hip_model_free(b.model->handle); b.model->handle = nullptr; }
+}
+inline void ggml_backend_free(dinov2_compat_backend&) {}                                 // inference.cpp:73
+#endif  // DINOV2_COMPAT_GGML_NAMES

@@ -79,7 +79,12 @@ typedef struct dinov2_hip_input {
     int32_t height;    /* multiples of patch_size, like img.size() in dinov2.cpp:908                       */
     int32_t width;
     int32_t layout;    /* enum dinov2_hip_layout                                                           */
-    int32_t on_device; /* 0: host memory (copied H2D each call); 1: device memory on the model's device    */
+    int32_t on_device; /* 0: host memory (copied H2D each call); 1: device memory on the model's device.
+                          Device inputs must be COMPLETE before the call: a session created with stream = NULL runs on
+                          its own non-blocking stream, which is not ordered after work the caller queued on another
+                          stream (e.g. the kernel that produced the images) -- synchronise that stream first, or hand
+                          the producer's stream to dinov2_hip_session_create.  Same for on_device outputs: read them
+                          after dinov2_hip_session_sync (or on the session's stream).                              */
 } dinov2_hip_input;
 
 /* Caller-allocated outputs; any pointer may be NULL.  Printing top-k stays in the caller. */
@@ -124,6 +129,35 @@ void *dinov2_hip_session_stream(dinov2_hip_session *session);
 /* -- predict (replaces dino_predict, dinov2.h:111-112 / dinov2.cpp:900-999) -------------------------- */
 int dinov2_hip_predict(dinov2_hip_session *session, const dinov2_hip_input *in, dinov2_hip_output *out,
                        uint32_t flags, char *err, size_t errlen);
+
+/* -- multi-device group (no reference counterpart: the reference is one backend, batch 1) -----------------
+ *    One host thread + one session per device inside the library; dinov2_hip_group_predict splits the caller's global batch
+ *    contiguously (device g owns images [g*B/G, (g+1)*B/G), remainder to the low ranks) and every device writes its results
+ *    into the caller's HOST buffers at its shard offset.  Images are independent forwards: no data-path collective.  With
+ *    `broadcast` = 1 (default) only device 0 parses / dequantises the GGUF; the packed weight arena reaches the others by ONE
+ *    RCCL broadcast over xGMI (single-process ncclCommInitAll + ncclBroadcast; librccl is dlopen'ed on first use).  A device
+ *    list that names a device twice (two sessions on one GPU) makes every entry read the file itself. */
+typedef struct dinov2_hip_group dinov2_hip_group;
+typedef struct dinov2_hip_group_opts {
+    dinov2_hip_load_opts load; /* compute dtype, classify, quirks; `device` and `skip_tensor_data` are set per rank          */
+    int32_t n_devices;         /* 0: every visible device                                                                     */
+    const int32_t *devices;    /* [n_devices] HIP ordinals, or NULL for 0 .. n_devices-1                                      */
+    int32_t broadcast;         /* 1: rank 0 loads, RCCL broadcast of the arena; 0: every rank loads the file                  */
+    int32_t reserved[8];
+} dinov2_hip_group_opts;
+void dinov2_hip_default_group_opts(dinov2_hip_group_opts *opts);
+int dinov2_hip_group_create(const char *gguf_path, const dinov2_hip_group_opts *opts, dinov2_hip_group **out, char *err,
+                            size_t errlen);
+void dinov2_hip_group_free(dinov2_hip_group *group);
+int dinov2_hip_group_size(const dinov2_hip_group *group);
+/* the model of one rank (hparams / labels are the same on every rank); owned by the group */
+dinov2_hip_model *dinov2_hip_group_model(dinov2_hip_group *group, int32_t rank);
+/* wall time of the load-time arena broadcast in ms; negative when every rank read the file itself */
+double dinov2_hip_group_broadcast_ms(const dinov2_hip_group *group);
+/* dino_predict over the whole group: host input [B, ...] (any dinov2_hip_layout), host outputs [B, ...]; returns when every
+ * shard has landed.  B < G leaves the high ranks idle.  One call at a time per group. */
+int dinov2_hip_group_predict(dinov2_hip_group *group, const dinov2_hip_input *in, dinov2_hip_output *out, uint32_t flags,
+                             char *err, size_t errlen);
 
 /* -- preprocessing (replaces dino_preprocess / dino_classify_preprocess, dinov2.h:93-96,
  *    dinov2.cpp:106-156, without OpenCV).  mode 0: resize to ((w/p)+1)*p x ((h/p)+1)*p; mode 1: resize to 256x256 ignoring

@@ -41,6 +41,10 @@ int dinov2_hip_op_probe_tr16(int16_t *out256);
 float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters);
 float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t nh, int32_t iters);
 
+/* preprocess_u8_kernel alone: raw 8-bit BGR [B, h, w, 3] -> normalised f32 BGR [B, oh, ow, 3] (mode 0 dino_preprocess,
+ * 1 dino_classify_preprocess; sizes from dinov2_hip_preprocess_size).  Replaces dinov2.cpp:106-156 on the device. */
+int dinov2_hip_op_preprocess_u8(int32_t mode, const uint8_t *bgr, int32_t B, int32_t h, int32_t w, int32_t patch, float *out);
+
 /* host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3.  yprev [H][8] (any full-rank block), gram [8][8] = yprev^T yprev,
  * ynext [H][8] = cov * (yprev R^-1) with gram = R^T R  ->  evals [3] largest Ritz values of cov on span(yprev), comp [3][H] their
  * unit Ritz vectors, each with its largest loading positive (H >= 8) */

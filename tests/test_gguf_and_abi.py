@@ -1,5 +1,6 @@
 """CPU suite, part 2: GGUF writer <-> oracle reader round trips, quant block known-answers, the C-ABI library
 (loads without a GPU, exports every declared symbol, loader error paths that never reach the device)."""
+import ctypes as C
 import os
 import re
 import struct
@@ -195,6 +196,36 @@ def test_cpp_compat_shim_compiles_with_plain_gxx(tmp_path):
     assert r.returncode == 1 and "failed to open" in r.stderr
 
 
+def _build_compat_opencv(tmp_path):
+    exe = str(tmp_path / "compat_cv")
+    libdir = os.path.join(ROOT, "dinov2.cpp_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "tests", "cpp", "opencv_stub"),
+                           "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "compat_opencv_smoke.cpp"), "-o", exe,
+                           "-L" + libdir, "-ldinov2_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_cpp_compat_opencv_branch_compiles(tmp_path):
+    """DINOV2_WITH_OPENCV + DINOV2_COMPAT_GGML_NAMES: the reference's `inference` main, call for call (cv::Mat / cv::Size
+    overloads of dinov2.h:93-112, dino_output::patch_tokens as a cv::Mat, the ggml_* lines of inference.cpp:60-73), compiles
+    warning-free against a minimal stand-in for the few cv:: types involved (this image has no OpenCV) and fails like the
+    reference on a missing model file."""
+    exe = _build_compat_opencv(tmp_path)
+    r = subprocess.run([exe, "-m", "/nonexistent.gguf"], capture_output=True, text=True)
+    assert r.returncode == 1 and "failed to open" in r.stderr and "failed to load model from" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_compat_opencv_branch_runs(tmp_path, golden_dir):
+    exe = _build_compat_opencv(tmp_path)
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    r = subprocess.run([exe, "-m", gguf], capture_output=True, text=True)  # features: 90x123 -> 98x126 -> 7 x 9 patches
+    assert r.returncode == 0 and "patch_tokens: 63 x 128 type 5 (input 98 x 126)" in r.stdout, r.stdout + r.stderr
+    assert "qntvr                  = 0" in r.stdout and "graph computation took" in r.stderr
+    r = subprocess.run([exe, "-m", gguf, "-c", "-k", "3"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count(" > label_") == 3, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_compat_shim_runs(tmp_path, golden_dir):
     exe = _build_compat_smoke(tmp_path)
@@ -324,3 +355,68 @@ def test_pca_ritz_step_matches_eigh(pkg, H):
     assert api.lib().dinov2_hip_op_pca_ritz(*(a.ctypes.data for a in a2), H, evals.ctypes.data, comp.ctypes.data) == 0
     assert np.isfinite(evals).all() and np.isfinite(comp).all()
     assert api.lib().dinov2_hip_op_pca_ritz(*(a.ctypes.data for a in args), 4, evals.ctypes.data, comp.ctypes.data) != 0
+
+
+def _patch_tensor_offset(blob: bytes, tensor: str, new_off: int) -> bytes:
+    """Overwrite the u64 data offset in the tensor-info record of `tensor` (name, u32 n_dims, n_dims x u64, u32 type, u64 off)."""
+    key = struct.pack("<Q", len(tensor)) + tensor.encode()
+    at = blob.index(key) + len(key)
+    nd, = struct.unpack_from("<I", blob, at)
+    at += 4 + 8 * nd + 4
+    return blob[:at] + struct.pack("<Q", new_off) + blob[at + 8:]
+
+
+@pytest.mark.parametrize("off", [2 ** 64 - 64, 2 ** 63, 2 ** 40])
+def test_crafted_tensor_offset_is_rejected(api, golden_dir, tmp_path, off):
+    """A tensor offset chosen so that data0 + offset + nbytes wraps around 2^64 (or simply lies far outside the file) must be a
+    FORMAT error in the loader and in the quantiser, before anything dereferences it (advisor finding, round 1)."""
+    blob = open(os.path.join(golden_dir, "tiny_gelu_noreg.gguf"), "rb").read()
+    evil = tmp_path / "evil.gguf"
+    evil.write_bytes(_patch_tensor_offset(blob, "embeddings.cls_token", off))
+    with pytest.raises(api.DinoError) as e:
+        api.Model(str(evil))
+    assert e.value.status == 2 and "cls_token" in str(e.value)
+    err = C.create_string_buffer(256)
+    assert api.lib().dinov2_hip_quantize(str(evil).encode(), str(tmp_path / "o.gguf").encode(), 8, err, 256) == 2
+    # an element count whose product wraps is refused as well
+    key = struct.pack("<Q", len("embeddings.cls_token")) + b"embeddings.cls_token"
+    at = blob.index(key) + len(key) + 4
+    huge = blob[:at] + struct.pack("<Q", 2 ** 62) + struct.pack("<Q", 8) + blob[at + 16:]
+    evil.write_bytes(huge)
+    with pytest.raises(api.DinoError) as e:
+        api.Model(str(evil))
+    assert e.value.status == 2
+
+
+@pytest.mark.parametrize("itype", [2, 8])
+def test_quantize_keeps_a_non_default_alignment(api, pkg, golden_dir, tmp_path, itype):
+    """A GGUF written with general.alignment = 64: both quantisers lay the output out with 64 too (the KV is copied through),
+    write identical bytes, and every tensor reads back as the quantised original (advisor finding, round 1: the output used
+    to be 32-aligned under a KV that said 64 -> silently corrupted tensors)."""
+    from oracle import gguf_np as G
+    Q = import_module(PKG_NAME + ".quantize")
+    gw = pkg.gguf_writer
+    _, kvs, tensors = Q._read(os.path.join(golden_dir, "tiny_gelu_reg4.gguf"))
+    w = gw.GGUFWriter(arch="dinov2", alignment=64)
+    for k, t, v in kvs:
+        if k != "general.architecture":
+            w.kvs.append((k, t, v))
+    w.add_uint32("general.alignment", 64)
+    for name, ne, gtype, raw in tensors:
+        w.add_raw_tensor(name, tuple(reversed(ne)), gtype, raw)
+    src = str(tmp_path / "al64.gguf")
+    w.write(src)
+    a, b = str(tmp_path / "py.gguf"), str(tmp_path / "cc.gguf")
+    assert Q.dino_model_quantize(src, a, itype)
+    err = C.create_string_buffer(256)
+    assert api.lib().dinov2_hip_quantize(src.encode(), b.encode(), itype, err, 256) == 0, err.value
+    assert open(a, "rb").read() == open(b, "rb").read()
+    fa, fs = G.GGUFFile(a), G.GGUFFile(src)
+    assert fa.kv["general.alignment"] == 64
+    for name, ts in fs.tensors.items():
+        ta = fa.tensors[name]
+        if Q.do_quantize(name, ts.ne):
+            assert ta.gtype == itype
+            assert np.array_equal(ta.raw, gw.quantize(ts.to_f32(), itype).reshape(-1)), name
+        else:
+            assert np.array_equal(ta.to_f32(), ts.to_f32()), name

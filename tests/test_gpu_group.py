@@ -1,0 +1,82 @@
+"""dinov2_hip_group_* (SURVEY 8(e)): the native multi-device driver behind the C-ABI -- one host thread + session per device,
+contiguous batch split, outputs written at the shard offsets of the caller's buffers, one-time RCCL broadcast of the weight
+arena.  On a 1-GPU box the split logic runs with the SAME device listed twice (every entry then reads the file itself) and
+the RCCL path with a one-device communicator; with >= 2 visible devices the real two-device broadcast runs too."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ndev():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_group_split_matches_single_session(api, golden_dir):
+    """Two ranks on device 0, ragged global batch 7 (4 + 3), classify and features, f32 and raw 8-bit input: every output equals
+    the single-session result bit for bit (B images are B independent forwards)."""
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    grp = api.Group(gguf, devices=[0, 0], classify=True)
+    assert grp.size == 2 and grp.broadcast_ms < 0  # duplicate device: no communicator, both entries read the file
+    sess = api.Session(api.Model(gguf, classify=True))
+    rng = np.random.default_rng(7)
+    imgs = rng.standard_normal((7, 3, 70, 98)).astype(np.float32)
+    for classify in (True, False):
+        ref = sess.predict(imgs, classify=classify, topk=3 if classify else 0)
+        got = grp.predict(imgs, classify=classify, topk=3 if classify else 0)
+        assert ref.keys() == got.keys()
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (classify, k)
+    raw = rng.integers(0, 256, (5, 61, 83, 3), dtype=np.uint8)
+    a = sess.predict(raw, classify=False, layout=api.U8_BGR_HWC, want=("patch_tokens",))
+    b = grp.predict(raw, classify=False, layout=api.U8_BGR_HWC, want=("patch_tokens",))
+    assert np.array_equal(a["patch_tokens"], b["patch_tokens"])
+    one = grp.predict(imgs[:1], classify=True)  # B < G: the second rank idles
+    assert np.array_equal(one["logits"], sess.predict(imgs[:1], classify=True)["logits"])
+    with pytest.raises(api.DinoError) as e:
+        grp.predict(np.zeros((2, 3, 60, 70), np.float32))
+    assert e.value.status == 4
+    grp.close()
+
+
+def test_group_rccl_broadcast_one_rank(api, golden_dir):
+    """broadcast = 1 with a single device: dlopen(librccl), ncclCommInitAll, the arena broadcast (root to itself) and teardown all
+    run; results equal the plain session's."""
+    gguf = os.path.join(golden_dir, "tiny_swiglu_reg4.gguf")
+    grp = api.Group(gguf, devices=[0], classify=True, broadcast=True)
+    assert grp.size == 1 and grp.broadcast_ms >= 0
+    imgs = np.random.default_rng(1).standard_normal((3, 3, 56, 84)).astype(np.float32)
+    ref = api.Session(api.Model(gguf, classify=True)).predict(imgs, classify=True)
+    got = grp.predict(imgs, classify=True)
+    assert np.array_equal(ref["logits"], got["logits"])
+
+
+def test_group_two_devices_broadcast(api, golden_dir):
+    """World = 2 when two devices are visible (skipped on the 1-GPU box): rank 1 never reads tensor data from the file -- its
+    arena arrives by ncclBroadcast over xGMI -- and its half of the batch must still equal device 0's single-session result."""
+    if _ndev() < 2:
+        pytest.skip("needs >= 2 visible devices")
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    grp = api.Group(gguf, devices=[0, 1], classify=True, broadcast=True)
+    assert grp.size == 2 and grp.broadcast_ms >= 0
+    imgs = np.random.default_rng(2).standard_normal((6, 3, 70, 70)).astype(np.float32)
+    ref = api.Session(api.Model(gguf, classify=True)).predict(imgs, classify=True)
+    got = grp.predict(imgs, classify=True)
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+
+
+def test_group_from_cpp(tmp_path, golden_dir):
+    """A C++ host (the reference's mains are C++) drives the group through include/dinov2_hip.h alone."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "group_smoke")
+    libdir = os.path.join(root, "dinov2.cpp_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "group_smoke.cpp"),
+                           "-o", exe, "-L" + libdir, "-ldinov2_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    r = subprocess.run([exe, os.path.join(golden_dir, "tiny_gelu_reg4.gguf")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GROUP_OK" in r.stdout, r.stdout + r.stderr

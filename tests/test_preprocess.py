@@ -1,6 +1,6 @@
 """dino_preprocess / dino_classify_preprocess without OpenCV.
 CPU: the C-ABI host implementation vs the numpy oracle (float64) vs torch bicubic (independent implementation).
-GPU: raw 8-bit images handed to predict (device preprocessing kernel) == host preprocessing + predict."""
+GPU (tests/test_gpu_configs.py): the device preprocessing kernel vs the same numpy oracle, alone and followed by the forward."""
 import os
 
 import numpy as np
@@ -62,18 +62,5 @@ def test_bicubic_equals_torch(api):
     assert np.abs(got - exp).max() < 3e-4
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("classify", [False, True])
-def test_device_preprocess_equals_host_then_predict(api, golden_dir, classify):
-    """inference.cpp:36-65 end to end: raw BGR bytes -> (device) preprocess -> forward == host preprocess -> forward."""
-    model = api.Model(os.path.join(golden_dir, "tiny_gelu_reg4.gguf"), classify=True)
-    sess = api.Session(model)
-    rng = np.random.default_rng(8)
-    raw = rng.integers(0, 256, (2, 90, 123, 3), dtype=np.uint8)
-    a = sess.predict(raw, classify=classify, layout=api.U8_BGR_HWC)
-    pre = np.stack([(api.dino_classify_preprocess if classify else api.dino_preprocess)(r) for r in raw])
-    b = sess.predict(pre, classify=classify, layout=api.BGR_HWC)
-    assert a["patch_tokens"].shape == b["patch_tokens"].shape
-    assert np.abs(a["patch_tokens"] - b["patch_tokens"]).max() < 2e-3
-    if classify:
-        assert np.abs(a["logits"] - b["logits"]).max() < 1e-3
+# The -m gpu checks of the DEVICE preprocessing kernel (kernel output and kernel -> forward, both against the oracle) live in
+# tests/test_gpu_configs.py: test_preprocess_kernel_vs_oracle, test_device_preprocess_then_forward_vs_oracle.
