@@ -671,23 +671,19 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
                                         hipStream_t st) {
     if (H != nh * 64 || T <= 0 || B <= 0) return hipErrorInvalidValue;
     if ((size_t)B * T * 3 * H * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;  // 32-bit staging cursors into qkv
-    // 8 waves (256 queries) per workgroup halve the K/V staging per query; 4 waves waste less on the ragged last query
-    // block.  DINOV2_HIP_ATTN_WAVES=4|8 overrides (tuning aid).
-    static const int forced = [] {
-        const char* e = getenv("DINOV2_HIP_ATTN_WAVES");
-        return e ? atoi(e) : 0;
-    }();
-    // (64-query workgroups, DINOV2_HIP_ATTN_WAVES=2, double the workgroup count at batch 1 but measured slower: 28 vs 25 us)
-    const int nwv = forced == 2 || forced == 4 || forced == 8 ? forced : 4;
+    // 4 waves = 128 queries per workgroup.  Measured alternatives (profiles/r01_gemm_tuning.md): 8 waves halve the K/V staging per
+    // query but waste more on the ragged last query block (1 374 tokens: 0.322 vs 0.296 ms); 2 waves double the workgroup count at
+    // batch 1 but run slower (28 vs 25 us).
+    constexpr int nwv = 4;
     // Two kernels, chosen by how many workgroups there are per CU.  Many (batch 32: 5 632 on 256 CUs): attention_kernel, 121
     // VGPRs, four workgroups per CU hide each other's latencies (0.296 ms vs 0.31-0.32).  Few (batch 1: 176): nothing to
     // overlap with, so the per-wave dependency chain decides and the software-pipelined attention2_kernel wins (22 vs 26 us).
-    // DINOV2_HIP_ATTN_V=1|2 forces one.
-    const char* ev = getenv("DINOV2_HIP_ATTN_V");  // read per launch: tests flip it
+    // DINOV2_HIP_ATTN_V=1|2 forces one (testing aid, include/dinov2_hip.h "Environment": the two kernels must agree bit for bit).
+    const char* ev = getenv("DINOV2_HIP_ATTN_V");  // read per launch: the test flips it
     const int forced_ver = ev ? atoi(ev) : 0;
     const long units = (long)((T + 127) / 128) * nh * B;
     const int ver = forced_ver ? forced_ver : units <= 512 ? 2 : 1;
-    if (ver == 2 && !forced) {
+    if (ver == 2) {
         const dim3 grid2(((T + 127) / 128) * nh * B), block2(256);
 #define DINO_ATT2(TT, LG) hipLaunchKernelGGL((attention2_kernel<TT, LG>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H)
         if (dt == DT_F16) { if (log2_scores) DINO_ATT2(_Float16, true); else DINO_ATT2(_Float16, false); }
@@ -698,8 +694,7 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     const dim3 grid(((T + nwv * 32 - 1) / (nwv * 32)) * nh * B), block(nwv * 64);
 #define DINO_ATT(TT, LG, NW) \
     hipLaunchKernelGGL((attention_kernel<TT, LG, NW>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
-#define DINO_ATT_N(TT, LG) \
-    { if (nwv == 8) DINO_ATT(TT, LG, 8); else if (nwv == 2) DINO_ATT(TT, LG, 2); else DINO_ATT(TT, LG, 4); }
+#define DINO_ATT_N(TT, LG) { DINO_ATT(TT, LG, 4); }
     if (dt == DT_F16) { if (log2_scores) DINO_ATT_N(_Float16, true) else DINO_ATT_N(_Float16, false) }
     else { if (log2_scores) DINO_ATT_N(__bf16, true) else DINO_ATT_N(__bf16, false) }
 #undef DINO_ATT_N

@@ -21,11 +21,6 @@
 #include "device_types.h"
 #include "kernels.h"
 
-// tuning aid, compile-time only (make variants): 1 = skip epilogue, 2 = skip in-loop staging, 4 = skip MFMA
-#ifndef DINO_GEMM_DBG
-#define DINO_GEMM_DBG 0
-#endif
-
 namespace dinov2 {
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI>
@@ -119,7 +114,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPT < 64 ? 2 * LPT : 0) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPT < 64 ? 3 * LPT : 0) : "memory");
         static_assert(NST <= 5, "extend the vmcnt dispatch above");
-        if (kt + NST - 1 < nk && !(DINO_GEMM_DBG & 2)) stage(nbuf, kt + NST - 1);
+        if (kt + NST - 1 < nk) stage(nbuf, kt + NST - 1);
         const char* s = smem + buf * STAGE;
         nbuf = buf;  // the buffer just consumed is the next to be refilled
         buf = buf + 1 == NST ? 0 : buf + 1;
@@ -135,8 +130,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             for (int i = 0; i < MREP; ++i)
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) {
-                    if constexpr ((DINO_GEMM_DBG & 4) != 0) acc[i][j][0] += (float)af[i][0] * (float)bf[j][0];
-                    else acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+                    acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
                 }
         }
     }
@@ -145,7 +139,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     //      row = m0 + wm*WTM + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),  col = n0 + wn*WTN + j*32 + (lane&31)
     const int colb = n0 + wn * WTN + fr;
     const int rowb = m0 + wm * WTM + 4 * fh;
-    if ((DINO_GEMM_DBG & 1) && acc[0][0][0] != 12345.678f) return;
 
     if constexpr (EPI == EPI_SWIGLU) {
         // W rows interleaved in 32-blocks: n-block 2q holds x1[32q..], n-block 2q+1 holds x2[32q..]
@@ -294,7 +287,7 @@ hipError_t gemm_init() {
 //      kernel (two launches; pays for a few left-over tiles)
 //   E  small-tile kernel only                               outputs / (256 tiles) / 0.5
 // Measured (M = 43 968): QKV 0.292 -> 0.285 ms (D), out-proj 0.129 -> 0.125 (C), FFN-out 0.393 -> 0.374 (C); ViT-g bf16 batch 8
-// 221 -> 244 images/s.  DINOV2_HIP_GEMM_SPLIT=0 restricts the choice to A / E, DINOV2_HIP_GEMM_TILE=128|256 forces E / A.
+// 221 -> 244 images/s.  DINOV2_HIP_GEMM_TILE=128|256 forces E / A (testing aid: include/dinov2_hip.h, "Environment").
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
@@ -304,10 +297,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
-    static const bool split_ok = [] {
-        const char* e = getenv("DINOV2_HIP_GEMM_SPLIT");
-        return !e || atoi(e) != 0;
-    }();
+    constexpr bool split_ok = true;
     // (the patch-embed epilogue maps row -> (image, patch): no row splits for it)
     const bool is_patch = epi == EPI_PATCH;
     const bool big_ok = !a.small_only && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
@@ -359,15 +349,10 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     // global -> LDS latency of its K loop.  64x128 tiles with 2 LDS stages (48 KiB: three workgroups per CU hide each other's
     // latency) when there are enough tiles, with 3 stages (72 KiB) when there are not (N = 1024 at batch 1: 176 tiles; the
     // K = 4096 GEMM 39.7 -> 33.8 us).  Measured at M = 1374: 128x128 / 64x128x2 / 64x128x3 = qkv 21.8 / 19.5 / 27.1 us,
-    // ffn-in 31.2 / 24.9 / 34.0, ffn-out 49.0 / 39.7 / 33.8.  DINOV2_HIP_GEMM_SMALL=0|1|2 forces a configuration.
-    static const int forced_small = [] {
-        const char* e = getenv("DINOV2_HIP_GEMM_SMALL");
-        return e ? atoi(e) : -1;
-    }();
+    // ffn-in 31.2 / 24.9 / 34.0, ffn-out 49.0 / 39.7 / 33.8.
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
-    int cfg = t128 >= 512 ? 0 : t64 >= 384 ? 1 : 2;
-    if (forced_small >= 0) cfg = forced_small;
+    const int cfg = t128 >= 512 ? 0 : t64 >= 384 ? 1 : 2;
     if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
     if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
     return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2, 2>(epi, a, st);

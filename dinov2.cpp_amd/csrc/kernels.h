@@ -31,7 +31,6 @@ struct GemmArgs {
     int P, T, R;        // EPI_PATCH token mapping
     int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale
     float qscale;
-    long long* ts;      // tuning aid: if non-null, block 0 / wave 0 writes s_memtime stamps of its first tiles here
     int small_only;     // launch_gemm internal: this is the tail of a split launch, use the small-tile kernel
 };
 

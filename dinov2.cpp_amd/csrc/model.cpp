@@ -1085,7 +1085,7 @@ extern "C" int dinov2_hip_pca3(dinov2_hip_session* s, const float* tokens, int32
     }
     HIP_TRY(hipSetDevice(s->model->device));
     hipStream_t st = s->stream;
-    static const bool trace = getenv("DINOV2_HIP_PCA_TRACE") != nullptr;
+    constexpr bool trace = false;  // flip to print the means / iteration / total times of a call to stderr
     const auto t_begin = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count(); };
     double t_setup = 0, t_iter = 0;

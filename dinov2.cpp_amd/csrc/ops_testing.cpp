@@ -185,9 +185,9 @@ extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32
     const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
     if (gemm_init() != hipSuccess) return -1.f;
     DevBuf dA, dW, dB, dX, dO;
-    // tuning aid: DINOV2_BENCH_PAD_A / _W = extra elements per row of A / W (row strides K + pad instead of the dense K)
-    const int padA = getenv("DINOV2_BENCH_PAD_A") ? atoi(getenv("DINOV2_BENCH_PAD_A")) : 0;
-    const int padW = getenv("DINOV2_BENCH_PAD_W") ? atoi(getenv("DINOV2_BENCH_PAD_W")) : 0;
+    // extra elements per row of A / W (row strides K + pad instead of the dense K): 0 in normal use; profiles/r02_gemm_kloop.md
+    // measured 64 (= 128 bytes) as neutral, i.e. no power-of-two-stride channel conflict to pad away
+    const int padA = 0, padW = 0;
     if (dA.alloc((size_t)M * (K + padA) * 2) != hipSuccess || dW.alloc((size_t)N * (K + padW) * 2) != hipSuccess ||
         dB.alloc((size_t)N * 4) != hipSuccess || dX.alloc((size_t)std::max(N, 4096) * 4 * 2) != hipSuccess ||
         dO.alloc((size_t)M * N * 4) != hipSuccess)
@@ -209,21 +209,6 @@ extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32
     for (auto t0 = std::chrono::steady_clock::now(); std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(100);) {
         for (int i = 0; i < 10; ++i) (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);  // ~100 ms warm-up (clock ramp)
         (void)hipDeviceSynchronize();
-    }
-    if (getenv("DINOV2_HIP_GEMM_TS")) {  // tuning aid: print s_memtime phase stamps of block 0 / wave 0
-        DevBuf dT;
-        if (dT.alloc(64 * 8) == hipSuccess) {
-            (void)hipMemset(dT.p, 0, 64 * 8);
-            a.ts = (long long*)dT.p;
-            (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);
-            (void)hipDeviceSynchronize();
-            long long h[64];
-            (void)hipMemcpy(h, dT.p, sizeof h, hipMemcpyDeviceToHost);
-            printf("ts deltas:");
-            for (int i = 1; i < 64 && h[i]; ++i) printf(" %lld", h[i] - h[i - 1]);
-            printf("\n");
-            a.ts = nullptr;
-        }
     }
     (void)hipEventRecord(e0, nullptr);
     for (int i = 0; i < iters; ++i) (void)launch_gemm(dt, (Epilogue)epilogue, a, nullptr);

@@ -20,9 +20,11 @@
 #include "device_types.h"
 #include "kernels.h"
 
-// The timing-only experiment switches this kernel carried while it was tuned (no staging / no MFMA / no fragment reads / deeper
-// prefetch / L2-resident operands ...) live in tools/probes/gemm2_dbg.hip; what they measured: profiles/r01_gemm_tuning.md,
-// profiles/r02_gemm_kloop.md.  The product kernel has one schedule.
+// tuning aid, compile-time only (make variant): 2 = skip in-loop staging, 4 = skip MFMA;
+// 1024 = single-owner staging experiment (one wave group stages per K-loop iteration; measured slower, see profiles/r01_gemm_tuning.md)
+#ifndef DINO_GEMM_DBG
+#define DINO_GEMM_DBG 0
+#endif
 
 namespace dinov2 {
 
@@ -77,16 +79,37 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 
     // ---- staging: 4 + 4 global_load_lds_dwordx4 per thread per K-tile, rows clamped to M ----
     unsigned xsrc[4], wsrc[4];  // byte offsets from p.A / p.W (both far below 4 GiB)
+#if DINO_GEMM_DBG & 1024  // experiment: in K-loop iteration kt only the wave group (kt & 1) stages -- its rows AND its SIMD partner's
+    unsigned xsrc2[4], wsrc2[4];
+#endif
     const int srow = lane >> 3;
     auto set_tile = [&](int m0, int n0) {
+#if DINO_GEMM_DBG & 256  // timing experiment only: every tile stages tile (0,0) -> operands stay L2-resident
+        m0 = 0;
+        n0 = 0;
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = (j * NW + wid) * 8 + srow;
+#if DINO_GEMM_DBG & 32768  // timing experiment only (wrong results): un-swizzled source, lanes 0-7 of a row read its 128 B in order
+            const int lc = lane & 7;
+#else
             const int lc = (lane & 7) ^ ((row >> 1) & 7);
+#endif
             int gm = m0 + row;
             gm = gm < M ? gm : M - 1;
             if (j < XREP) xsrc[j] = (unsigned)gm * lda2 + lc * 16;
             wsrc[j] = (unsigned)(n0 + row) * ldw2 + lc * 16;
+#if DINO_GEMM_DBG & 1024
+            {
+                const int row2 = (j * NW + (wid ^ 4)) * 8 + srow;
+                const int lc2 = (lane & 7) ^ ((row2 >> 1) & 7);
+                int gm2 = m0 + row2;
+                gm2 = gm2 < M ? gm2 : M - 1;
+                if (j < XREP) xsrc2[j] = (unsigned)gm2 * lda2 + lc2 * 16;
+                wsrc2[j] = (unsigned)(n0 + row2) * ldw2 + lc2 * 16;
+            }
+#endif
         }
     };
     auto stage = [&](int buf, int kt) {
@@ -102,12 +125,21 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 
     // one of the 8 wave-instructions of a K-tile (0-3: activation rows, 4-7: weight rows); j is a literal at every call
     auto piece = [&](int buf, int kt, int j) {
+        if (DINO_GEMM_DBG & 2) return;
         if (j < 4 && j >= XREP) return;  // 192-row tiles have three activation pieces
         char* dst = smem + buf * STAGE + (j < 4 ? 0 : BM * ROWB) + ((j & 3) * NW + wid) * 8 * ROWB;
         const char* src = (j < 4 ? (const char*)p.A + xsrc[j & 3] : (const char*)p.W + wsrc[j & 3]) + (size_t)kt * (BK * 2);
         glds16(src, dst);
     };
 
+#if DINO_GEMM_DBG & 1024
+    auto piece2 = [&](int buf, int kt, int j) {  // the same piece of the SIMD partner (wave wid ^ 4)
+        if (j < 4 && j >= XREP) return;
+        char* dst = smem + buf * STAGE + (j < 4 ? 0 : BM * ROWB) + ((j & 3) * NW + (wid ^ 4)) * 8 * ROWB;
+        const char* src = (j < 4 ? (const char*)p.A + xsrc2[j & 3] : (const char*)p.W + wsrc2[j & 3]) + (size_t)kt * (BK * 2);
+        glds16(src, dst);
+    };
+#endif
     const int wx = wid >> 2, ww = wid & 3;
     const int grp = wid >> 2;  // waves 0-3 / 4-7: the two waves that share each SIMD
     const int fr = lane & 31, fh = lane >> 5;
@@ -124,6 +156,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         waddr[ks] = lds0 + (unsigned)woff + ch;
     }
 
+#if DINO_GEMM_DBG & 8  // tuning aid: block 0 / thread 0 stamps s_memtime at phase boundaries of its first tiles
+    int tsn = 0;
+#define DINO_TS() \
+    if (p.ts && blockIdx.x == 0 && tid == 0 && tsn < 64) p.ts[tsn++] = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define DINO_TS()
+#endif
 
     const int nk = K / BK;  // even (checked by the launcher): the last K-tile sits in stage 1, stage 0 is free for the
                             // next tile's first K-tile while the epilogue works in stage 1
@@ -134,6 +173,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         stage(0, 0);
     }
     for (int tix = bidx; tix < chunkn; tix += nb_x) {
+        DINO_TS();
         int m0, n0;
         tile_mn(chunk0 + tix, m0, n0);
 
@@ -146,13 +186,17 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                 for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
 
         u32x4 xf0[4], wf0[WREP], xf1[4], wf1[WREP];
+#if DINO_GEMM_DBG & 2048  // timing experiment only: no fragment ds_reads (MFMAs run on whatever these registers hold)
+        for (int i = 0; i < 4; ++i) xf0[i] = xf1[i] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        for (int i = 0; i < WREP; ++i) wf0[i] = wf1[i] = u32x4{(unsigned)tid, 5u, 6u, 7u};
+#endif
 
         // ---- main loop ---------------------------------------------------------------------------------------------
         // Rules followed for the inline-asm reads (cdna_hip_programming.md 5.7): every asm read is waited for by an asm
         // s_waitcnt before its first consumer, and a sched_barrier(0) follows each wait so no MFMA is hoisted above it.
 #define DINO_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 #define DINO_LOAD_FRAGS(XF, WF, BUFOFF, KS)                                      \
-    {                                                                            \
+    if (!(DINO_GEMM_DBG & 2048)) {                                               \
         const unsigned xa__ = xaddr[KS] + (BUFOFF), wa__ = waddr[KS] + (BUFOFF); \
         DINO_DSR(XF[0], xa__, 0);                                                \
         DINO_DSR(XF[1], xa__, 4096);                                             \
@@ -165,8 +209,18 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");    \
     __builtin_amdgcn_sched_barrier(0);
     constexpr int NRD = XREP + WREP;  // fragment reads per k-step
+#if DINO_GEMM_DBG & 512  // experiment: raise the wave's priority around its MFMA runs
+#define DINO_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#else
+#define DINO_PRIO(P)
+#endif
+#if DINO_GEMM_DBG & 4  // timing experiment only: no MFMA (one VALU op keeps the fragment registers and the accumulator live)
+#define DINO_MFMA1(XF, WF, I, J) \
+    acc[J][I][0] += __builtin_bit_cast(float, WF[J][0]) * __builtin_bit_cast(float, XF[I][0]);
+#else
 #define DINO_MFMA1(XF, WF, I, J) \
     acc[J][I] = E::mfma32(__builtin_bit_cast(vec8, WF[J]), __builtin_bit_cast(vec8, XF[I]), acc[J][I]);
+#endif
     // Eight MFMAs of one k-step with staging instructions in four slots: S0 before the 1st MFMA, S1 after the 3rd, S2
     // after the 6th, S3 after the 8th.  A global_load_lds occupies its wave's issue port for ~60-185 cycles, so wave
     // group 0 (waves 0-3) stages in S0,S1,S2 and group 1 (waves 4-7, their SIMD partners) in S1,S2,S3: the two waves of a
@@ -178,27 +232,38 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     {                                              \
         S0;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
+        DINO_PRIO(1);                              \
         DINO_MFMA1(XF, WF, 0, 0)                   \
         DINO_MFMA1(XF, WF, 0, 1)                   \
         DINO_MFMA1(XF, WF, 1, 0)                   \
+        DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S1;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
+        DINO_PRIO(1);                              \
         DINO_MFMA1(XF, WF, 1, 1)                   \
         DINO_MFMA1(XF, WF, 2, 0)                   \
         DINO_MFMA1(XF, WF, 2, 1)                   \
+        DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S2;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
+        DINO_PRIO(1);                              \
         if (XREP == 4) {                           \
             DINO_MFMA1(XF, WF, 3, 0)               \
             DINO_MFMA1(XF, WF, 3, 1)               \
         }                                          \
+        DINO_PRIO(0);                              \
         __builtin_amdgcn_sched_barrier(0);         \
         S3;                                        \
         __builtin_amdgcn_sched_barrier(0);         \
     }
     // slot helpers: piece ja for group 0 / piece jb for group 1 of K-tile KT into stage BUF when COND holds
+#if DINO_GEMM_DBG & 1024
+#define DINO_SLOT_A(COND, BUF, KT, JA) if ((COND) && own) { piece(BUF, KT, JA); piece2(BUF, KT, JA); }
+#define DINO_SLOT_B(COND, BUF, KT, JB)
+#define DINO_SLOT_AB(COND, BUF, KT, JA, JB) DINO_SLOT_A(COND, BUF, KT, JA)
+#else
 #define DINO_SLOT_A(COND, BUF, KT, JA) if ((COND) && grp == 0) piece(BUF, KT, JA)
 #define DINO_SLOT_B(COND, BUF, KT, JB) if ((COND) && grp == 1) piece(BUF, KT, JB)
 #define DINO_SLOT_AB(COND, BUF, KT, JA, JB) \
@@ -206,10 +271,12 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         if (grp == 0) piece(BUF, KT, JA);   \
         else piece(BUF, KT, JB);            \
     }
+#endif
 #define DINO_MFMAS(XF, WF) DINO_MFMAS_P(XF, WF, , , , )
 
         __syncthreads();  // K-tile 0 of this tile has landed (vmcnt(0) precedes the barrier; also drains the previous
                           // tile's stores) and every wave has left the previous tile's epilogue slices in stage 1
+        DINO_TS();
         piece(1, 1, 0);
         piece(1, 1, 1);
         piece(1, 1, 2);
@@ -217,6 +284,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         for (int kt = 0; kt < nk; ++kt) {
             const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = (unsigned)((kt + 1) & 1) * STAGE;
             const int nb = (kt + 1) & 1;
+#if DINO_GEMM_DBG & 1024
+            const bool own = (kt & 1) == grp;
+#endif
             const bool more = kt + 1 < nk;      // K-tile kt+1 exists: its pieces 0-2 were issued behind the last barrier,
                                                 // pieces 3-7 go out with the first two MFMA groups of this iteration
             DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
@@ -234,7 +304,18 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
             // of K-tile kt+1 has landed; after the barrier everyone's has.
             DINO_WAIT_LGKM(0);
+#if DINO_GEMM_DBG & 8192  // timing experiment only (wrong results): the newest 8 pieces stay in flight across the barrier
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#elif DINO_GEMM_DBG & 16384  // timing experiment only (wrong results): 16 pieces (two K-tiles) stay in flight
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#elif DINO_GEMM_DBG & 64  // timing experiment only: no barrier at all
+#elif DINO_GEMM_DBG & 16  // timing experiment only (wrong results): barrier WITHOUT waiting for the in-flight K-tile
+            __builtin_amdgcn_s_barrier();
+#else
             __syncthreads();
+#endif
             DINO_LOAD_FRAGS(xf0, wf0, nxt, 0);  // after the last K-tile this reads LDS that is never used
             __builtin_amdgcn_sched_barrier(0);
             // MFMAs are never inside a branch (the accumulators would be copied at the join): only the staging
@@ -259,6 +340,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             piece(0, 0, 7);
         }
         DINO_WAIT_LGKM(0);
+        DINO_TS();
 #undef DINO_DSR
 #undef DINO_LOAD_FRAGS
 #undef DINO_WAIT_LGKM
@@ -448,7 +530,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        DINO_TS();
     }  // persistent tile loop
+#undef DINO_TS
 }
 
 template <typename T, int EPI, int XREP>
