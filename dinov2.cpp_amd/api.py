@@ -41,7 +41,7 @@ class DinoError(RuntimeError):
 class LoadOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("compute_dtype", C.c_int32), ("classify", C.c_int32),
                 ("skip_tensor_data", C.c_int32), ("quirk_pool_const_divisor", C.c_int32),
-                ("quirk_pool_includes_registers", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("quirk_pool_includes_registers", C.c_int32), ("batch_invariant", C.c_int32), ("reserved", C.c_int32 * 9)]
 
 
 class HParams(C.Structure):
@@ -129,6 +129,7 @@ def lib():
     fp = C.POINTER(C.c_float)
     L.dinov2_hip_op_gemm.argtypes = [i32, i32, fp, fp, fp, fp, C.c_int64, fp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                      C.c_float]
+    L.dinov2_hip_op_gemm_ksplit.argtypes = L.dinov2_hip_op_gemm.argtypes
     L.dinov2_hip_op_attention.argtypes = [i32, fp, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_layernorm.argtypes = [i32, fp, fp, fp, fp, i32, i32, C.c_float]
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
@@ -137,6 +138,8 @@ def lib():
     L.dinov2_hip_op_preprocess_u8.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     L.dinov2_hip_op_gemm_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_gemm_bench.restype = C.c_float
+    L.dinov2_hip_op_gemm_bench_ksplit.argtypes = [i32] * 6
+    L.dinov2_hip_op_gemm_bench_ksplit.restype = C.c_float
     L.dinov2_hip_op_attention_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_attention_bench.restype = C.c_float
     _lib = L
@@ -181,13 +184,15 @@ class Model:
     """dino_model counterpart (owning handle)."""
 
     def __init__(self, path: str, *, device: int = 0, dtype: int = F16, classify: bool = True,
-                 skip_tensor_data: bool = False, pool_const_divisor: bool = True, pool_includes_registers: bool = True):
+                 skip_tensor_data: bool = False, pool_const_divisor: bool = True, pool_includes_registers: bool = True,
+                 batch_invariant: bool = False):
         L = lib()
         o = LoadOpts()
         L.dinov2_hip_default_load_opts(C.byref(o))
         o.device, o.compute_dtype, o.classify = device, dtype, int(classify)
         o.skip_tensor_data = int(skip_tensor_data)
         o.quirk_pool_const_divisor, o.quirk_pool_includes_registers = int(pool_const_divisor), int(pool_includes_registers)
+        o.batch_invariant = int(batch_invariant)
         h = C.c_void_p()
         err = _errbuf()
         rc = L.dinov2_hip_model_load(path.encode(), C.byref(o), C.byref(h), err, len(err))
@@ -266,11 +271,13 @@ class Group:
     """dinov2_hip_group: N devices behind one handle -- one host thread + session per device inside the library, the global
     batch split contiguously, outputs landing at the shard offsets of the caller's arrays."""
 
-    def __init__(self, path: str, devices=None, *, dtype: int = F16, classify: bool = True, broadcast: bool = True):
+    def __init__(self, path: str, devices=None, *, dtype: int = F16, classify: bool = True, broadcast: bool = True,
+                 batch_invariant: bool = False):
         L = lib()
         o = GroupOpts()
         L.dinov2_hip_default_group_opts(C.byref(o))
         o.load.compute_dtype, o.load.classify = dtype, int(classify)
+        o.load.batch_invariant = int(batch_invariant)
         o.broadcast = int(broadcast)
         if devices is not None:
             self._devs = (C.c_int32 * len(devices))(*devices)

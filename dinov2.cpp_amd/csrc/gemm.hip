@@ -23,8 +23,13 @@
 
 namespace dinov2 {
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+// KS = 2: intra-workgroup split-K for the few-tile, long-K GEMMs of a small batch.  The workgroup is TWO wave groups of WM x WN
+// waves; group g multiplies K-tiles [g nk/2, (g+1) nk/2) of the SAME output tile out of its own LDS ring, both in step (shared
+// barriers), and at the end group 1 hands its accumulators to group 0 through LDS: result = acc_lo + acc_hi, one extra f32
+// rounding against the un-split sum.  No global traffic, no extra launch, deterministic -- but not the bits of the un-split
+// kernel, so it is used only when the caller allows it (GemmArgs.allow_ksplit; dinov2_hip_load_opts.batch_invariant = 0).
+template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI, int KS = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma clang fp contract(off)  // position-independent results: see gemm2.hip
     using E = Elem<T>;
     using vec8 = typename E::vec8;
@@ -37,11 +42,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // glds wave-instructions per wave per tile
     static_assert(NREP == 2, "SwiGLU pairing and the register budget assume a 64-wide wave tile");
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = KS == 1 ? 0 : wid_all / NW;  // K-split group
+    const int wid = KS == 1 ? wid_all : wid_all - grp * NW;
     const int M = p.M, N = p.N, K = p.K;
     const size_t lda = p.lda ? p.lda : K, ldw = p.ldw ? p.ldw : K;
 
@@ -70,10 +77,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         bsrc[j] = (const char*)p.W + ((size_t)gn * ldw) * 2 + lc * 16;
     }
 
+    char* const smem = smem_all + grp * (NST * STAGE);  // this group's LDS ring
+    const int kt_lo = grp * ((K / BK) / KS);            // this group's K range (the launcher guarantees (K / 64) % KS == 0)
     auto stage = [&](int buf, int kt) {
         char* sA = smem + buf * STAGE;
         char* sB = sA + BM * ROWB;
-        const size_t koff = (size_t)kt * (BK * 2);
+        const size_t koff = (size_t)(kt_lo + kt) * (BK * 2);
 #pragma unroll
         for (int j = 0; j < AI; ++j) glds16(asrc[j] + koff, sA + (j * NW + wid) * 8 * ROWB);
 #pragma unroll
@@ -102,7 +111,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // done reading the buffer that tile kt+NST-1 is about to overwrite.  Raw s_barrier: __syncthreads() would drain vmcnt.
     constexpr int LPT = AI + BI;  // glds instructions per wave per tile
     static_assert((NST - 2) * LPT < 64, "vmcnt is 6 bits");
-    const int nk = K / BK;
+    const int nk = (K / BK) / KS;
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
@@ -133,6 +142,30 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                     acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
                 }
         }
+    }
+
+    if constexpr (KS == 2) {
+        // group 1 -> LDS -> group 0: element (wave, accumulator register q) of lane l at float index (wave * NQ + q) * 64 + l
+        constexpr int NQ = MREP * NREP * 16;
+        static_assert(NW * NQ * 256 <= NST * STAGE, "the hand-over buffer reuses group 0's ring");
+        float* const xch = (float*)smem_all + (size_t)wid * NQ * 64 + lane;
+        __syncthreads();  // every wave has finished its last fragment reads: group 0's ring is free
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < MREP; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[((i * NREP + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < MREP; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * NREP + j) * 16 + r) * 64];  // acc_lo + acc_hi
     }
 
     // ---- epilogue: acc[i][j][r] is C[row, col] with
@@ -215,14 +248,14 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1>
 static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-    const dim3 grid(ntn * ntm), block(WM * WN * 64);
-    const size_t lds = NST * (size_t)(BM + BN) * 128;
+    const dim3 grid(ntn * ntm), block(WM * WN * 64 * KS);
+    const size_t lds = KS * NST * (size_t)(BM + BN) * 128;
 #define DINO_LAUNCH(E)                                                                             \
     case E:                                                                                        \
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E>), grid, block, lds, st, a);         \
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E, KS>), grid, block, lds, st, a);     \
         break;
     switch (epi) {
         DINO_LAUNCH(EPI_PATCH)
@@ -236,13 +269,13 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1>
 static hipError_t set_attr_cfg() {
-    const int lds = NST * (BM + BN) * 128;
+    const int lds = KS * NST * (BM + BN) * 128;
     hipError_t e = hipSuccess;
 #define DINO_ATTR(E)                                                                                          \
     if (e == hipSuccess)                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E>),            \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E, KS>),        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DINO_ATTR(EPI_PATCH)
     DINO_ATTR(EPI_QKV)
@@ -266,6 +299,8 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 2>();
     if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 3>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3, 2>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -353,6 +388,12 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
     const int cfg = t128 >= 512 ? 0 : t64 >= 384 ? 1 : 2;
+    // Fewer tiles than CUs and a long K loop (batch 1: the two N = hidden GEMMs, 176 tiles, 16 / 64 K-tiles): one wave per SIMD
+    // walks a serial, latency-bound K loop.  Split K inside the workgroup (KS = 2, see gemm_kernel) when the caller allows a
+    // summation order that depends on the batch size: FFN-out 33.7 -> 25.3 us, attn-out 13.8 -> 9.8 us at M = 1 374 (ViT-L p50 3.03 -> 2.79 ms).
+    // (never for the tail of a large launch -- small_only -- or a large batch's last rows would be summed in another order than its first)
+    if (a.allow_ksplit && !a.small_only && cfg == 2 && t64 < 256 && a.K >= 1024 && (a.K / 64) % 2 == 0)
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3, 2>(epi, a, st);
     if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
     if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
     return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2, 2>(epi, a, st);

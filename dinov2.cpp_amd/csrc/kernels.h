@@ -32,6 +32,8 @@ struct GemmArgs {
     int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale
     float qscale;
     int small_only;     // launch_gemm internal: this is the tail of a split launch, use the small-tile kernel
+    int allow_ksplit;   // 1: few-tile, long-K shapes may split K inside the workgroup (result = acc_lo + acc_hi: deterministic, but
+                        // not the bits of the un-split sum).  0 (default): every kernel sums K in the same order.
 };
 
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);

@@ -197,6 +197,7 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
     m->device = opts.device;
     m->quirk_const_div = opts.quirk_pool_const_divisor != 0;
     m->quirk_pool_regs = opts.quirk_pool_includes_registers != 0;
+    m->batch_invariant = opts.batch_invariant != 0;
 
     const int H = (int)hp.hidden_size, L = (int)hp.num_hidden_layers, nh = (int)hp.num_attention_heads;
     const int ps = (int)hp.patch_size, R = (int)hp.num_register_tokens;
@@ -618,7 +619,7 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
             Scope sc(s, K_OPROJ_GEMM);
             GemmArgs a{};
             a.A = s->att; a.W = ly.o_w; a.bias = ly.o_b; a.out = s->x; a.aux = ly.ls1;
-            a.M = d.M; a.N = H; a.K = H; a.ldo = H;
+            a.M = d.M; a.N = H; a.K = H; a.ldo = H; a.allow_ksplit = !m->batch_invariant;
             HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
         }
         {
@@ -636,7 +637,7 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
             Scope sc(s, K_FC2_GEMM);
             GemmArgs a{};
             a.A = s->hid; a.W = ly.fc2_w; a.bias = ly.fc2_b; a.out = s->x; a.aux = ly.ls2;
-            a.M = d.M; a.N = H; a.K = F; a.ldo = H;
+            a.M = d.M; a.N = H; a.K = F; a.ldo = H; a.allow_ksplit = !m->batch_invariant;
             HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
         }
     }

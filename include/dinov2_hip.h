@@ -58,7 +58,11 @@ typedef struct dinov2_hip_load_opts {
                                  receive the arena by RCCL broadcast (dinov2_hip_model_arena)                        */
     int32_t quirk_pool_const_divisor;      /* 1 (default): pooled = sum / (img_size/patch)^2  (dinov2.cpp:794,800-803) */
     int32_t quirk_pool_includes_registers; /* 1 (default): register tokens are pooled too      (dinov2.cpp:772-776)     */
-    int32_t reserved[10];
+    int32_t batch_invariant; /* 0 (default): at small batches the two N = hidden GEMMs split their K loop inside the workgroup
+                                (result = acc_lo + acc_hi): reproducible run to run, but an image's last bits can then depend
+                                on the size of the batch it came in.  1: every kernel sums K in one order -- B images == B
+                                independent forwards bit for bit at any batch size (costs ~0.5 ms of batch-1 latency on ViT-L) */
+    int32_t reserved[9];
 } dinov2_hip_load_opts;
 
 /* dino_hparams (dinov2.h:25-47) plus what the loader derives from the tensor list. */

@@ -132,32 +132,59 @@ __global__ __launch_bounds__(768) void gemm_lw2(const _Float16* __restrict__ A, 
 #define DSR(DST, ADDR, OFF) \
     if (!(VARIANT & 16)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
 
+#define READ_KS(XF, WF, KS, SO)                                                  \
+    {                                                                            \
+        const unsigned ch__ = (unsigned)((((KS) * 2 + hh) ^ sw) << 4) + (SO);    \
+        const unsigned xa__ = xbase + ch__, wa__ = wbase + ch__;                 \
+        DSR(WF[0], wa__, 0);                                                     \
+        DSR(WF[1], wa__, 4096);                                                  \
+        DSR(XF[0], xa__, 0);                                                     \
+        DSR(XF[1], xa__, 4096);                                                  \
+        DSR(XF[2], xa__, 8192);                                                  \
+        if (XREP == 4) DSR(XF[XREP - 1], xa__, 12288);                           \
+    }
+#define MMA_KS(XF, WF)                                                                                                   \
+    {                                                                                                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        _Pragma("unroll") for (int i = 0; i < XREP; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) {                 \
+            if (VARIANT & 32) acc[i][j][0] += __builtin_bit_cast(float, XF[i][0]) * __builtin_bit_cast(float, WF[j][0]); \
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, XF[i]), __builtin_bit_cast(f16x8, WF[j]), acc[i][j], 0, 0, 0); \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }
+#if VARIANT & 64  // fragments double-buffered inside the K-tile (one k-step of lookahead, as gemm2_kernel has)
+    u32x4 xg[XREP], wg2[2];
+    constexpr int NR = XREP + 2;
+    for (int kt = 0; kt < nk; ++kt) {
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned so = (unsigned)(kt & 1) * (unsigned)STAGE;
+        READ_KS(xf, wf, 0, so)
+        READ_KS(xg, wg2, 1, so)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR));
+        MMA_KS(xf, wf)
+        READ_KS(xf, wf, 2, so)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR));
+        MMA_KS(xg, wg2)
+        READ_KS(xg, wg2, 3, so)
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR));
+        MMA_KS(xf, wf)
+        asm volatile("s_waitcnt lgkmcnt(0)");
+        MMA_KS(xg, wg2)
+    }
+#else
     for (int kt = 0; kt < nk; ++kt) {
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const unsigned so = (unsigned)(kt & 1) * (unsigned)STAGE;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const unsigned ch = (unsigned)(((ks * 2 + hh) ^ sw) << 4) + so;
-            const unsigned xa = xbase + ch, wa = wbase + ch;
-            DSR(wf[0], wa, 0);
-            DSR(wf[1], wa, 4096);
-            DSR(xf[0], xa, 0);
-            DSR(xf[1], xa, 4096);
-            DSR(xf[2], xa, 8192);
-            if (XREP == 4) DSR(xf[XREP - 1], xa, 12288);
+            READ_KS(xf, wf, ks, so)
             asm volatile("s_waitcnt lgkmcnt(0)");
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < XREP; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (VARIANT & 32) acc[i][j][0] += __builtin_bit_cast(float, xf[i][0]) * __builtin_bit_cast(float, wf[j][0]);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, xf[i]), __builtin_bit_cast(f16x8, wf[j]), acc[i][j], 0, 0, 0);
-                }
-            __builtin_amdgcn_sched_barrier(0);
+            MMA_KS(xf, wf)
         }
     }
+#endif
 #pragma unroll
     for (int i = 0; i < XREP; ++i)
 #pragma unroll
