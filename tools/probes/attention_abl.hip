@@ -1,3 +1,7 @@
+// attention_abl.hip -- instrumented copy of dinov2.cpp_amd/csrc/attention.hip (round 2): attention_kernel with the timing-only
+// ablation switches DINO_ATT_ABL (1 no exp, 2 no staging, 4 no barrier, 8 no V reads, 16 no K reads, 32 no MFMA, 64 no max / sum /
+// convert) and the wave-count macros DINO_ATT1_WAVES / DINO_ATT3_WAVES.  Build it in place of csrc/attention.hip into a variant library
+// (see tools/README.md); results: profiles/r02_attention_anatomy.md.  NOT part of the product.
 // attention.hip -- fused multi-head self-attention (flash-style, never materialises the T x T scores) for gfx950.
 //
 // Replaces the whole non-flash branch of `attn` in the reference, /root/reference/dinov2.cpp:479-543:
@@ -104,8 +108,11 @@ static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
 }
 
 #ifndef DINO_ATT_ABL
-#define DINO_ATT_ABL 0  // attention2_kernel, timing-only ablations (WRONG results): 1 no exp, 2 no staging, 4 no barrier, 8 no V
-                        // reads, 16 no K reads.  The same study of attention_kernel: tools/probes/attention_abl.hip
+#define DINO_ATT_ABL 0  // timing-only ablations (WRONG results): 1 no exp, 2 no staging, 4 no barrier, 8 no V reads, 16 no K reads,
+                        // 32 no MFMA (attention_kernel only), 64 no max / sum / convert VALU work (attention_kernel only)
+#endif
+#ifndef DINO_ATT1_WAVES
+#define DINO_ATT1_WAVES 4
 #endif
 #ifndef DINO_ATT3_WAVES
 #define DINO_ATT3_WAVES 2  // waves per workgroup of the 64-queries-per-wave kernel (2: 128-query blocks, 4: 256-query blocks)
@@ -238,9 +245,9 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
     auto tile = [&](int jt, auto masked_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         DINO_TS(0)
-        __syncthreads();
+        if (!(DINO_ATT_ABL & 4)) __syncthreads();
         DINO_TS(1)
-        if (!MASKED) stage((jt + 1) & 1, jt + 1);
+        if (!MASKED && !(DINO_ATT_ABL & 2)) stage((jt + 1) & 1, jt + 1);
         if (idle_wave) return;  // a wave whose 32 queries all lie past the last token only helps with staging and barriers
         const char* sK = smem + (jt & 1) * 2 * TILEB;
         const char* sV = sK + TILEB;
@@ -251,9 +258,14 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const vec8 kf = *(const vec8*)(sK + kaddr[ks] + kb * 32 * ROWB);
+                const vec8 kf = (DINO_ATT_ABL & 16) ? qf[0][(ks + kb) & 3] : *(const vec8*)(sK + kaddr[ks] + kb * 32 * ROWB);
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
+                    if (DINO_ATT_ABL & 32) {
+                        if (ks == 0) s[u][kb] = negm[u];
+                        s[u][kb][ks] += (float)kf[0] * (float)qf[u][ks][1];
+                        continue;
+                    }
                     if (ks == 0) s[u][kb] = mfma32_c(kf, qf[u][0], negm[u]);  // D != C: no copy of the 16 -m_run registers per chain
                     else s[u][kb] = E::mfma32(kf, qf[u][ks], s[u][kb]);
                 }
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
             mfma_settle(s[u]);
-            const float mx = max_halves(max32(s[u]));  // tile maximum relative to m_run
+            const float mx = (DINO_ATT_ABL & 64) ? s[u][0][3] : max_halves(max32(s[u]));  // tile maximum relative to m_run
             const bool first = jt == 0;             // m_run = 0 is not a real reference yet: take the tile maximum, whatever it is
             const bool need = first || mx > THR;
             if (__any(need)) {  // wave-uniform; lanes that do not need it shift by d = 0 (alpha = 1)
@@ -299,9 +311,9 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = LOG2 ? __builtin_amdgcn_exp2f(s[u][kb][r]) : __expf(s[u][kb][r]);
+                    const float pv = (DINO_ATT_ABL & 1) ? s[u][kb][r] * 0.5f : LOG2 ? __builtin_amdgcn_exp2f(s[u][kb][r]) : __expf(s[u][kb][r]);
                     s[u][kb][r] = pv;
-                    ps[r & 3] += pv;
+                    if (!(DINO_ATT_ABL & 64) || r < 2) ps[r & 3] += pv;
                 }
             l_run[u] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         }
@@ -314,10 +326,15 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #pragma unroll
             for (int u = 0; u < QB; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pf[u][j] = E::from_f32(s[u][t >> 1][(t & 1) * 8 + j]);
+                for (int j = 0; j < 8; ++j)
+                    pf[u][j] = (DINO_ATT_ABL & 64) ? __builtin_bit_cast(vec8, f32x4{s[u][t >> 1][(t & 1) * 8], s[u][t >> 1][(t & 1) * 8 + 1],
+                                                                                       s[u][t >> 1][(t & 1) * 8 + 4], s[u][t >> 1][(t & 1) * 8 + 5]})[j]
+                                                   : E::from_f32(s[u][t >> 1][(t & 1) * 8 + j]);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 vec8 vf;
+                if (DINO_ATT_ABL & 8) vf = qf[0][(t + db) & 3];
+                else
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     const s16x4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -329,7 +346,10 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
                     vf[half * 4 + 3] = v4[3];
                 }
 #pragma unroll
-                for (int u = 0; u < QB; ++u) o[u][db] = E::mfma32(vf, pf[u], o[u][db]);
+                for (int u = 0; u < QB; ++u) {
+                    if (DINO_ATT_ABL & 32) { o[u][db][t] += (float)vf[0] * (float)pf[u][1]; continue; }
+                    o[u][db] = E::mfma32(vf, pf[u], o[u][db]);
+                }
             }
         }
         DINO_TS(5)
@@ -708,7 +728,7 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     // 4 waves = 128 queries per workgroup.  Measured alternatives (profiles/r01_gemm_tuning.md): 8 waves halve the K/V staging per
     // query but waste more on the ragged last query block (1 374 tokens: 0.322 vs 0.296 ms); 2 waves double the workgroup count at
     // batch 1 but run slower (28 vs 25 us).
-    constexpr int nwv = 4;
+    constexpr int nwv = DINO_ATT1_WAVES;
     // Two kernels, chosen by how many workgroups there are per CU.  Many (batch 32: 5 632 on 256 CUs): attention_kernel, 121
     // VGPRs, four workgroups per CU hide each other's latencies (0.296 ms vs 0.31-0.32).  Few (batch 1: 176): nothing to
     // overlap with, so the per-wave dependency chain decides and the software-pipelined attention2_kernel wins (22 vs 26 us).
@@ -737,7 +757,7 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     const dim3 grid(((T + nwv * 32 - 1) / (nwv * 32)) * nh * B), block(nwv * 64);
 #define DINO_ATT(TT, LG, NW) \
     hipLaunchKernelGGL((attention_kernel<TT, LG, NW>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
-#define DINO_ATT_N(TT, LG) { DINO_ATT(TT, LG, 4); }
+#define DINO_ATT_N(TT, LG) { DINO_ATT(TT, LG, DINO_ATT1_WAVES); }
     if (dt == DT_F16) { if (log2_scores) DINO_ATT_N(_Float16, true) else DINO_ATT_N(_Float16, false) }
     else { if (log2_scores) DINO_ATT_N(__bf16, true) else DINO_ATT_N(__bf16, false) }
 #undef DINO_ATT_N

@@ -1,0 +1,86 @@
+// mfma_valu_mix.hip -- do the MFMAs of one wave overlap with the VALU work of the OTHER waves of its SIMD on gfx950?
+// Every wave repeats an attention-like tile: phase A = 16 MFMA 32x32x16 (4 chains of 4 dependent MFMAs), phase B = NV VALU
+// instructions (a third of them v_exp_f32).  MODE 0: both phases; 1: MFMAs only; 2: VALU only.  Reported: SIMD cycles per tile
+// per wave (block span / (REP * waves per SIMD)).  If phases of different waves overlap, MODE 0 at 4 waves per SIMD costs
+// ~max(MODE 1, MODE 2); if they do not, the sum.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_valu_mix.bin mfma_valu_mix.hip
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#define REP 128
+
+template <int MODE, int DEP>
+__global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed) {
+    f16v acc[4];
+    float r[32];
+    for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 16; ++i) acc[c][i] = seed * i;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) r[i] = seed + threadIdx.x * 1e-3f + i;
+    h8 a = {1, 2, 3, 4, 5, 6, 7, 8};
+    __syncthreads();
+    const long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < REP; ++it) {
+        if (MODE != 2) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[c]) : "v"(a));
+        }
+        if (MODE != 1) {
+            if (DEP) {  // the VALU phase reads the accumulators (as the softmax does): forces the wave to wait for its MFMAs
+#pragma unroll
+                for (int c = 0; c < 4; ++c) asm volatile("s_nop 7\n s_nop 7\n v_add_f32 %0, %0, %1" : "+v"(r[c]) : "v"(acc[c][0]));
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 31]));
+#pragma unroll
+            for (int i = 0; i < 32; i += 2) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(r[i]) : "v"(r[i + 1]));
+        }
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) s += r[i];
+    for (int c = 0; c < 4; ++c) s += acc[c][3];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) { cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0; cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1; }
+}
+
+template <int MODE, int DEP>
+static void run(const char* name) {
+    float* out; long long* cyc;
+    hipMalloc(&out, 1024 * 4 * 256); hipMalloc(&cyc, 8 * 256 * 32);
+    printf("%-34s", name);
+    for (int wps : {1, 2, 3, 4}) {
+        hipLaunchKernelGGL((k<MODE, DEP>), dim3(256), dim3(256 * wps), 0, 0, out, cyc, 0.5f);
+        hipLaunchKernelGGL((k<MODE, DEP>), dim3(256), dim3(256 * wps), 0, 0, out, cyc, 0.5f);
+        hipDeviceSynchronize();
+        std::vector<long long> c(256 * 32); hipMemcpy(c.data(), cyc, 8 * 256 * 32, hipMemcpyDeviceToHost);
+        double avg = 0;
+        for (int b = 0; b < 256; ++b) {
+            long long lo = c[b * 32], hi = c[b * 32 + 1];
+            for (int w = 1; w < 4 * wps; ++w) { lo = std::min(lo, c[b * 32 + 2 * w]); hi = std::max(hi, c[b * 32 + 2 * w + 1]); }
+            avg += (double)(hi - lo);
+        }
+        avg /= 256;
+        printf("  wps=%d: %7.1f", wps, avg / (REP * (double)wps));
+    }
+    printf("   cycles per tile per wave\n");
+    hipFree(out); hipFree(cyc);
+}
+int main() {
+    run<1, 0>("16 MFMA only");
+    run<2, 0>("112 VALU only (32 exp)");
+    run<0, 0>("both, VALU independent of MFMA");
+    run<0, 1>("both, VALU reads the accumulators");
+    return 0;
+}
