@@ -305,6 +305,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
                 }
             l_run[u] += (ps[0] + ps[1]) + (ps[2] + ps[3]);
         }
+        __builtin_amdgcn_s_setprio(1);  // the PV section (converts, V^T gathers, MFMAs) ahead of the other waves' softmax: +1.5 % measured
         DINO_TS(4)
         // ---- O^T += V^T P^T : 4 k-steps of 16 keys; lane's 8 k-slots of step t = score regs (t&1)*8 .. +7 of
         //      block t>>1, i.e. keys 16t + 4hh + {0..3} and 16t + 8 + 4hh + {0..3}.  Every V^T fragment feeds all QB query blocks.
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
                 for (int u = 0; u < QB; ++u) o[u][db] = E::mfma32(vf, pf[u], o[u][db]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         DINO_TS(5)
     };
     stage(0, 0);

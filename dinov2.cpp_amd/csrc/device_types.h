@@ -26,6 +26,9 @@ struct Elem<_Float16> {
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
     }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {  // 16x16x32: D[4 (l >> 4) + e][l & 15], rows = A rows
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
     static __device__ __forceinline__ _Float16 from_f32(float x) { return (_Float16)x; }
     static __device__ __forceinline__ float to_f32(_Float16 x) { return (float)x; }
 };
@@ -36,6 +39,9 @@ struct Elem<__bf16> {
     using vec4 = bf16x4;
     static __device__ __forceinline__ f32x16 mfma32(vec8 a, vec8 b, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ f32x4 mfma16(vec8 a, vec8 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
     static __device__ __forceinline__ __bf16 from_f32(float x) { return (__bf16)x; }
     static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }

@@ -1,22 +1,22 @@
-// gemm2.hip -- the main f16/bf16 MFMA GEMM of the forward pass (256x256x64 tile, persistent), second generation.
+// gemm2.hip -- the main f16/bf16 MFMA GEMM of the forward pass (256x256x64 tile, persistent), third generation.
 //
-// Same contract and epilogues as gemm.hip (which stays as the 128x128 edge-guarded kernel for small / odd shapes).
-// Every structural choice below comes from a measurement on MI355X (profiles/r01_gemm_tuning.md):
+// Same contract and epilogues as gemm.hip (which stays as the edge-guarded small-tile kernel for small / odd shapes).
+// Every structural choice below comes from a measurement on MI355X (profiles/r01_gemm_tuning.md, profiles/r02_gemm_kloop.md):
 //   * PERSISTENT workgroups (grid = min(tiles, 256), one per CU).  Retiring and relaunching a 512-thread / 128 KiB-LDS
 //     workgroup per tile cost about as much as the whole K = 1024 loop (fixed 31 us per tile -> 15 us).
-//   * OPERAND SWAP: the weight tile is the MFMA A operand and the activation tile the B operand, so a 32x32
-//     accumulator block holds C^T: lane l owns ONE token row (l & 31) and, per 4-register group, FOUR CONSECUTIVE
-//     output columns -> vector bias / LayerScale loads and 8/16-byte LDS writes in the epilogue.
-//   * REGISTER DOUBLE-BUFFERED FRAGMENTS with HAND-COUNTED waits: the six ds_read_b128 of k-step s+1 are issued (inline
-//     asm) before the eight MFMAs of k-step s, across the K-tile boundary too, and waited for with s_waitcnt lgkmcnt(6).
-//     hipcc's own wait insertion put lgkmcnt(0) right behind freshly issued reads.
-//   * LOADS TWO K-TILES AHEAD, ONE BARRIER PER K-TILE: global_load_lds for K-tile t+2 is issued right after the barrier
-//     that publishes K-tile t+1; the NEXT output tile's first K-tile is issued after the last barrier of the current one,
-//     so its HBM/L2 latency (8k cycles when exposed) hides under the epilogue.
+//   * MFMA 16x16x32, NOT 32x32x16: the same 8-phase schedule measured 1 066 / 1 137 TFLOP/s (4 096^3 / 8 192^3, f16, random
+//     operands) with the 32x32x16 shape and 1 242 / 1 333 with 16x16x32; the previous generation of this kernel (32x32x16, one
+//     barrier per K-tile, register double-buffered fragments) 1 098 / 1 110.
+//   * OPERAND SWAP: the weight fragment is the MFMA A operand and the activation fragment the B operand, so an accumulator
+//     block holds C^T: lane l owns ONE token (l & 15) and FOUR CONSECUTIVE output columns -> vector bias / LayerScale loads
+//     and 8/16-byte LDS writes in the epilogue.
+//   * THE LOCAL GUIDE'S 8-PHASE SCHEDULE: quadrant phases, half-tile staging by global_load_lds one and a half K-tiles ahead with
+//     ONE counted s_waitcnt vmcnt(4) per K-tile, raw s_barrier (no vmcnt(0) drain), the two waves of a SIMD half a phase apart.
+//     The NEXT output tile's first K-tile is staged during the last phases, so its HBM/L2 latency hides under the epilogue.
 //   * FULL-LINE EPILOGUE THROUGH LDS: each wave transposes its 128x64 result through a private 8 KiB slice of the idle
-//     second LDS stage and moves whole 128-byte lines (lane l owns 16 B of row 8*it + (l >> 3)); residual-stream reads are
+//     second LDS buffer and moves whole 128-byte lines (lane l owns 16 B of row 8*it + (l >> 3)); residual-stream reads are
 //     issued one pass ahead of the stores that would otherwise force a vmcnt(0) drain (gfx950 counts stores on vmcnt).
-// Fragment layouts, LDS swizzle and the XCD-aware tile order are those of gemm.hip.
+// LDS swizzle and the XCD-aware tile order are those of gemm.hip.
 #include "device_types.h"
 #include "kernels.h"
 
@@ -26,10 +26,10 @@
 
 namespace dinov2 {
 
-// XREP = 32-row MFMA blocks per wave along M: 4 -> 256-row tiles (the main configuration), 3 -> 192-row tiles, used by the
+// XREP = 32-token blocks per wave along M: 4 -> 256-row tiles (the main configuration), 3 -> 192-row tiles, used by the
 // dispatcher for the LAST partial round of a launch (688 tiles of 256 rows on 256 CUs are 2.69 rounds -> 3; two rounds of
-// 256-row tiles plus one round of 192-row tiles cover the same rows in 2.79).  Same instruction schedule minus the fourth
-// activation fragment; same K order, so a row's bits do not depend on the tile height.
+// 256-row tiles plus one round of 192-row tiles cover the same rows in 2.79).  Same schedule with a half-height second token
+// half; same K order, so a row's bits do not depend on the tile height.
 template <typename T, int EPI, int XREP>
 static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem) {
     // No implicit mul+add -> fma contraction anywhere in this kernel: the unrolled epilogue instances would otherwise be
@@ -39,12 +39,10 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
-    constexpr int BM = 64 * XREP, BN = 256, BK = 64, NW = 8;
-    constexpr int ROWB = BK * 2;
-    constexpr int STAGE = 512 * ROWB;  // 64 KiB per K-tile (X rows at 0, W rows at BM * ROWB), two stages
-    constexpr int WREP = 2;                  // wave tile: 32 * XREP tokens x 64 output columns
-    constexpr int WOFF = BM * ROWB;          // LDS offset of the weight rows inside a stage
-
+    constexpr int BM = 64 * XREP, BN = 256, BK = 64;
+    constexpr int BUF = 65536;               // one K-tile: four half-tile slots of 16 KiB -- X0, X1 (token halves), W0, W1 (column halves)
+    constexpr int RX1 = 32 * (XREP - 2);     // tokens per wave-row in the second token half: 64 (256-row tiles) or 32 (192-row tiles)
+    constexpr int NI1 = RX1 / 16;            // 16-token blocks of the second half: 4 or 2
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // opaque: when two bodies run back to back (gemm2_mixed_kernel) nothing lane-derived is
@@ -75,249 +73,241 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         n0 = n * BN;
     };
 
-    // ---- staging: 4 + 4 global_load_lds_dwordx4 per thread per K-tile, rows clamped to M ----
-    unsigned xsrc[4], wsrc[4];  // byte offsets from p.A / p.W (both far below 4 GiB)
-    const int srow = lane >> 3;
+    const int wx = wid >> 2, ww = wid & 3;  // wave tile: 32 * XREP tokens (wave-row wx) x 64 output columns (wave-column ww)
+
+    // ---- staging: a half-tile is an image of 8-row x 128-byte pieces (one global_load_lds_dwordx4 wave-instruction each, lane ->
+    // row lane >> 3, 16-byte chunk lane & 7, the chunk XOR-swizzled on the SOURCE side).  Image row r of token half a belongs to
+    // wave-row r / RX (RX = 64, or 32 for the second half of a 192-row tile), local token r % RX; image row r of column half b
+    // to wave-column r >> 5, local column r & 31.  A wave issues pieces 2 wid and 2 wid + 1 of a 16-piece half-tile (piece wid of
+    // the 8-piece one).  Rows are clamped to M.
+    unsigned src[4][2];  // byte offsets from p.A / p.W of this wave's pieces: [X0, X1, W0, W1][piece]
     auto set_tile = [&](int m0, int n0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = (j * NW + wid) * 8 + srow;
-            const int lc = (lane & 7) ^ ((row >> 1) & 7);
-            int gm = m0 + row;
-            gm = gm < M ? gm : M - 1;
-            if (j < XREP) xsrc[j] = (unsigned)gm * lda2 + lc * 16;
-            wsrc[j] = (unsigned)(n0 + row) * ldw2 + lc * 16;
-        }
-    };
-    auto stage = [&](int buf, int kt) {
-        char* sX = smem + buf * STAGE;
-        char* sW = sX + BM * ROWB;
-        const char* ga = (const char*)p.A + (size_t)kt * (BK * 2);
-        const char* gw = (const char*)p.W + (size_t)kt * (BK * 2);
+        for (int h = 0; h < 4; ++h)
 #pragma unroll
-        for (int j = 0; j < XREP; ++j) glds16(ga + xsrc[j], sX + (j * NW + wid) * 8 * ROWB);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) glds16(gw + wsrc[j], sW + (j * NW + wid) * 8 * ROWB);
+            for (int pc = 0; pc < 2; ++pc) {
+                const bool half8 = h == 1 && RX1 == 32;  // the 8-piece half-tile
+                if (half8 && pc == 1) continue;
+                const int r = (half8 ? wid : 2 * wid + pc) * 8 + (lane >> 3);
+                const int ch = (lane & 7) ^ ((r >> 1) & 7);
+                if (h < 2) {
+                    const int rx = h == 0 ? 64 : RX1;
+                    int gm = m0 + (r / rx) * (32 * XREP) + h * 64 + (r % rx);
+                    gm = gm < M ? gm : M - 1;
+                    src[h][pc] = (unsigned)gm * lda2 + ch * 16;
+                } else {
+                    src[h][pc] = (unsigned)(n0 + (r >> 5) * 64 + (h - 2) * 32 + (r & 31)) * ldw2 + ch * 16;
+                }
+            }
+    };
+    auto stage = [&](int h, int kt, int buf) {  // h is a literal at every call site
+        const char* base = (h < 2 ? (const char*)p.A : (const char*)p.W) + (size_t)kt * (BK * 2);
+        const bool half8 = h == 1 && RX1 == 32;
+        char* dst = smem + buf * BUF + h * 16384 + (half8 ? wid : 2 * wid) * 1024;
+        glds16(base + src[h][0], dst);
+        if (!half8) glds16(base + src[h][1], dst + 1024);
     };
 
-    // one of the 8 wave-instructions of a K-tile (0-3: activation rows, 4-7: weight rows); j is a literal at every call
-    auto piece = [&](int buf, int kt, int j) {
-        if (j < 4 && j >= XREP) return;  // 192-row tiles have three activation pieces
-        char* dst = smem + buf * STAGE + (j < 4 ? 0 : BM * ROWB) + ((j & 3) * NW + wid) * 8 * ROWB;
-        const char* src = (j < 4 ? (const char*)p.A + xsrc[j & 3] : (const char*)p.W + wsrc[j & 3]) + (size_t)kt * (BK * 2);
-        glds16(src, dst);
-    };
-
-    const int wx = wid >> 2, ww = wid & 3;
-    const int grp = wid >> 2;  // waves 0-3 / 4-7: the two waves that share each SIMD
-    const int fr = lane & 31, fh = lane >> 5;
-    const int sw = (fr >> 1) & 7;
-    const int xoff = (wx * (32 * XREP) + fr) * ROWB;
-    const int woff = (ww * 64 + fr) * ROWB;  // + WOFF goes into the instruction offset
-
+    // ---- fragment addresses (16x16x32 MFMA: lane -> row lane & 15, k quarter lane >> 4; 16-byte chunk (4 ks + kq) ^ swizzle)
+    const int fr = lane & 15, kq = lane >> 4, sw = (fr >> 1) & 7;
     const unsigned lds0 = (unsigned)(uintptr_t)(DINO_LDS_AS char*)smem;
-    unsigned xaddr[4], waddr[4];  // per k-step LDS byte address of this lane's first X / W fragment row (stage 0)
+    unsigned xa[2][2], wa[2];  // [token half][k-step] / [k-step]: this lane's fragment row in buffer 0 (16-row blocks at + 2048 each)
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const unsigned ch = (unsigned)(((ks * 2 + fh) ^ sw) << 4);
-        xaddr[ks] = lds0 + (unsigned)xoff + ch;
-        waddr[ks] = lds0 + (unsigned)woff + ch;
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned ch = (unsigned)(((ks * 4 + kq) ^ sw) << 4);
+        xa[0][ks] = lds0 + (unsigned)((wx * 64 + fr) * 128) + ch;
+        xa[1][ks] = lds0 + 16384u + (unsigned)((wx * RX1 + fr) * 128) + ch;
+        wa[ks] = lds0 + 32768u + (unsigned)((ww * 32 + fr) * 128) + ch;  // column half 1 at + 16384
     }
 
-
-    const int nk = K / BK;  // even (checked by the launcher): the last K-tile sits in stage 1, stage 0 is free for the
-                            // next tile's first K-tile while the epilogue works in stage 1
+    const int nk = K / BK;  // even (checked by the launcher): the last K-tile sits in buffer 1, where the epilogue's slices go, and
+                            // buffer 0 is free for the next output tile's first K-tile
     if (bidx < chunkn) {
         int pm0, pn0;
         tile_mn(chunk0 + bidx, pm0, pn0);
         set_tile(pm0, pn0);
-        stage(0, 0);
+        stage(0, 0, 0);
+        stage(2, 0, 0);
+        stage(1, 0, 0);
+        stage(3, 0, 0);
     }
     for (int tix = bidx; tix < chunkn; tix += nb_x) {
         int m0, n0;
         tile_mn(chunk0 + tix, m0, n0);
+        const bool has_next = tix + nb_x < chunkn;
 
-        f32x16 acc[WREP][4];  // [.][3] untouched (and eliminated) when XREP == 3
+        // acc[a][b][i][j][e] = C[m0 + wx * 32 XREP + 64 a + 16 i + (lane & 15)][n0 + ww * 64 + 32 b + 16 j + 4 (lane >> 4) + e]
+        // (OPERAND SWAP: the weight fragment is the MFMA A operand, so a lane owns one token and four CONSECUTIVE output columns:
+        // vector bias / LayerScale loads and 8 / 16-byte LDS writes in the epilogue)
+        f32x4 acc[2][2][4][2];
 #pragma unroll
-        for (int j = 0; j < WREP; ++j)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int i = 0; i < XREP; ++i)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.f;
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        u32x4 xf[4][2], wf[2][2];  // fragments of ONE quadrant (64 tokens x 32 columns x the whole K-tile): 48 registers
 
-        u32x4 xf0[4], wf0[WREP], xf1[4], wf1[WREP];
-
-        // ---- main loop ---------------------------------------------------------------------------------------------
-        // Rules followed for the inline-asm reads (cdna_hip_programming.md 5.7): every asm read is waited for by an asm
-        // s_waitcnt before its first consumer, and a sched_barrier(0) follows each wait so no MFMA is hoisted above it.
+        // ---- main loop: the local guide's 8-phase schedule with its own MFMA shape --------------------------------------------
+        // One phase = one quadrant (token half a, column half b) over the whole K-tile: its fragment reads and one half-tile of
+        // staging in the MEM section, its 16 MFMAs 16x16x32 in the MMA section, a workgroup barrier after each section.  The two
+        // wave-rows (= the two waves of every SIMD) run half a phase apart (wave-row 1 takes one extra barrier up front), so one
+        // wave per SIMD is in its MMA section while its partner reads and stages.  Per K-tile t:
+        //   phase 0  reads X0(t) 8 + W0(t) 4 -> quadrant (0,0) -> stages X1(t+1)
+        //   phase 1  reads W1(t) 4           -> quadrant (0,1) -> stages W0(t+1)
+        //   phase 2  reads X1(t) 8           -> quadrant (1,1) -> stages X0(t+2)
+        //   phase 3  reads W0(t) 4           -> quadrant (1,0) -> stages W1(t+2), then s_waitcnt vmcnt(4): K-tile t+1 has landed
+        // A half-tile slot is re-staged two phases after its last read, and a K-tile is read one phase after the counted wait that
+        // retires it.  Past the end of this tile's K the staging continues with the NEXT output tile's K-tile 0 (buffer 0), so its
+        // latency hides under the last phases and the epilogue; that tile's X0 / W1 of K-tile 1 follow after the epilogue, whose
+        // LDS slices live in buffer 1.
+        // Measured (tools/probes/gemm8p.hip, gemm8p16.hip; profiles/r02_gemm_kloop.md): this schedule with 32x32x16 MFMAs runs at the
+        // level of the previous one-barrier-per-K-tile loop (1 066 / 1 137 TFLOP/s at 4 096^3 / 8 192^3); with 16x16x32 MFMAs
+        // 1 242 / 1 333.
 #define DINO_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-#define DINO_LOAD_FRAGS(XF, WF, BUFOFF, KS)                                      \
-    {                                                                            \
-        const unsigned xa__ = xaddr[KS] + (BUFOFF), wa__ = waddr[KS] + (BUFOFF); \
-        DINO_DSR(XF[0], xa__, 0);                                                \
-        DINO_DSR(XF[1], xa__, 4096);                                             \
-        DINO_DSR(XF[2], xa__, 8192);                                             \
-        if (XREP == 4) DINO_DSR(XF[3], xa__, 12288);                             \
-        DINO_DSR(WF[0], wa__, WOFF);                                             \
-        DINO_DSR(WF[1], wa__, WOFF + 4096);                                      \
+#define DINO_READ_X(A_, BO)                                                   \
+    {                                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                    \
+            const unsigned a__ = xa[A_][ks] + (BO);                           \
+            DINO_DSR(xf[0][ks], a__, 0);                                      \
+            DINO_DSR(xf[1][ks], a__, 2048);                                   \
+            if ((A_) == 0 || NI1 == 4) {                                      \
+                DINO_DSR(xf[2][ks], a__, 4096);                               \
+                DINO_DSR(xf[3][ks], a__, 6144);                               \
+            }                                                                 \
+        }                                                                     \
     }
-#define DINO_WAIT_LGKM(N)                                         \
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");    \
-    __builtin_amdgcn_sched_barrier(0);
-    constexpr int NRD = XREP + WREP;  // fragment reads per k-step
-#define DINO_MFMA1(XF, WF, I, J) \
-    acc[J][I] = E::mfma32(__builtin_bit_cast(vec8, WF[J]), __builtin_bit_cast(vec8, XF[I]), acc[J][I]);
-    // Eight MFMAs of one k-step with staging instructions in four slots: S0 before the 1st MFMA, S1 after the 3rd, S2
-    // after the 6th, S3 after the 8th.  A global_load_lds occupies its wave's issue port for ~60-185 cycles, so wave
-    // group 0 (waves 0-3) stages in S0,S1,S2 and group 1 (waves 4-7, their SIMD partners) in S1,S2,S3: the two waves of a
-    // SIMD are not both stuck in a staging instruction at the same moment.  Measured honestly: a burst of eight behind
-    // the barrier vs. these slots is worth ~5 % in the micro-benchmark and nothing in-model; with the staging removed
-    // altogether the kernel runs 786 -> 1182 TFLOP/s (cycles -20 %, clock +17 %), and neither the load latency (no-wait
-    // experiment), nor the LDS reads (free), nor the barrier (6 %) explains it -- see profiles/r01_gemm_tuning.md.
-#define DINO_MFMAS_P(XF, WF, S0, S1, S2, S3)       \
-    {                                              \
-        S0;                                        \
-        __builtin_amdgcn_sched_barrier(0);         \
-        DINO_MFMA1(XF, WF, 0, 0)                   \
-        DINO_MFMA1(XF, WF, 0, 1)                   \
-        DINO_MFMA1(XF, WF, 1, 0)                   \
-        __builtin_amdgcn_sched_barrier(0);         \
-        S1;                                        \
-        __builtin_amdgcn_sched_barrier(0);         \
-        DINO_MFMA1(XF, WF, 1, 1)                   \
-        DINO_MFMA1(XF, WF, 2, 0)                   \
-        DINO_MFMA1(XF, WF, 2, 1)                   \
-        __builtin_amdgcn_sched_barrier(0);         \
-        S2;                                        \
-        __builtin_amdgcn_sched_barrier(0);         \
-        if (XREP == 4) {                           \
-            DINO_MFMA1(XF, WF, 3, 0)               \
-            DINO_MFMA1(XF, WF, 3, 1)               \
-        }                                          \
-        __builtin_amdgcn_sched_barrier(0);         \
-        S3;                                        \
-        __builtin_amdgcn_sched_barrier(0);         \
+#define DINO_READ_W(B_, BO)                                                   \
+    {                                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                    \
+            const unsigned a__ = wa[ks] + (BO) + (B_) * 16384u;               \
+            DINO_DSR(wf[0][ks], a__, 0);                                      \
+            DINO_DSR(wf[1][ks], a__, 2048);                                   \
+        }                                                                     \
     }
-    // slot helpers: piece ja for group 0 / piece jb for group 1 of K-tile KT into stage BUF when COND holds
-#define DINO_SLOT_A(COND, BUF, KT, JA) if ((COND) && grp == 0) piece(BUF, KT, JA)
-#define DINO_SLOT_B(COND, BUF, KT, JB) if ((COND) && grp == 1) piece(BUF, KT, JB)
-#define DINO_SLOT_AB(COND, BUF, KT, JA, JB) \
-    if (COND) {                             \
-        if (grp == 0) piece(BUF, KT, JA);   \
-        else piece(BUF, KT, JB);            \
+#define DINO_BAR()                              \
+    {                                           \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
     }
-#define DINO_MFMAS(XF, WF) DINO_MFMAS_P(XF, WF, , , , )
+#define DINO_MMA(A_, B_)                                                                                                     \
+    {                                                                                                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                     \
+        _Pragma("unroll") for (int i = 0; i < ((A_) == 0 ? 4 : NI1); ++i)                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                        \
+            acc[A_][B_][i][j] = E::mfma16(__builtin_bit_cast(vec8, wf[j][ks]), __builtin_bit_cast(vec8, xf[i][ks]), acc[A_][B_][i][j]); \
+        /* pin the MFMAs INSIDE this section: pure register ops otherwise sink below the barrier that ends it */             \
+        _Pragma("unroll") for (int i = 0; i < ((A_) == 0 ? 4 : NI1); ++i)                                                    \
+            asm volatile("" : "+v"(acc[A_][B_][i][0]), "+v"(acc[A_][B_][i][1]));                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                                       \
+    }
+#define DINO_PHASE_END(A_, B_)                                  \
+    DINO_BAR()                                                  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    DINO_MMA(A_, B_)                                            \
+    DINO_BAR()
 
-        __syncthreads();  // K-tile 0 of this tile has landed (vmcnt(0) precedes the barrier; also drains the previous
-                          // tile's stores) and every wave has left the previous tile's epilogue slices in stage 1
-        piece(1, 1, 0);
-        piece(1, 1, 1);
-        piece(1, 1, 2);
-        DINO_LOAD_FRAGS(xf0, wf0, 0u, 0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const unsigned cur = (unsigned)(kt & 1) * STAGE, nxt = (unsigned)((kt + 1) & 1) * STAGE;
-            const int nb = (kt + 1) & 1;
-            const bool more = kt + 1 < nk;      // K-tile kt+1 exists: its pieces 0-2 were issued behind the last barrier,
-                                                // pieces 3-7 go out with the first two MFMA groups of this iteration
-            DINO_LOAD_FRAGS(xf1, wf1, cur, 1);  // 12 reads in flight at most
-            DINO_WAIT_LGKM(NRD);                  // the older six (k-step 0) have returned
-            DINO_MFMAS_P(xf0, wf0, DINO_SLOT_A(more, nb, kt + 1, 3), DINO_SLOT_AB(more, nb, kt + 1, 4, 3),
-                         DINO_SLOT_AB(more, nb, kt + 1, 5, 4), DINO_SLOT_B(more, nb, kt + 1, 5));
-            DINO_LOAD_FRAGS(xf0, wf0, cur, 2);
-            DINO_WAIT_LGKM(NRD);
-            DINO_MFMAS_P(xf1, wf1, DINO_SLOT_A(more, nb, kt + 1, 6), DINO_SLOT_AB(more, nb, kt + 1, 7, 6),
-                         DINO_SLOT_B(more, nb, kt + 1, 7), );
-            DINO_LOAD_FRAGS(xf1, wf1, cur, 3);
-            DINO_WAIT_LGKM(NRD);
-            DINO_MFMAS(xf0, wf0);               // no staging here: slack for K-tile kt+1 to land before the barrier
-            // k-step-3 fragments (issued one MFMA group ago) must be in registers before the barrier: after it nobody
-            // reads stage kt&1 any more, so K-tile kt+2 may overwrite it.  __syncthreads adds vmcnt(0): this wave's part
-            // of K-tile kt+1 has landed; after the barrier everyone's has.
-            DINO_WAIT_LGKM(0);
-            __syncthreads();
-            DINO_LOAD_FRAGS(xf0, wf0, nxt, 0);  // after the last K-tile this reads LDS that is never used
-            __builtin_amdgcn_sched_barrier(0);
-            // MFMAs are never inside a branch (the accumulators would be copied at the join): only the staging
-            // instructions are conditional.  pk = K-tile to fetch (kt+2, or 0 of the NEXT output tile after the last
-            // barrier, when stage 0 is idle), pb = its stage.
-            const bool last = kt + 1 == nk;
-            const bool fetch = last ? (tix + nb_x < chunkn) : (kt + 2 < nk);
-            if (last && fetch) {
+        // every wave has left the previous tile's epilogue slices (buffer 1); K-tile 0 of this tile is in flight or in buffer 0
+        DINO_BAR()
+        stage(0, 1, 1);
+        stage(3, 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but those four: K-tile 0 has landed (and the previous tile's stores)
+        DINO_BAR()
+        if (wx == 1) DINO_BAR()  // wave-row 1 runs one barrier behind wave-row 0
+
+        for (int t = 0; t < nk; ++t) {
+            const unsigned bo = (unsigned)(t & 1) * (unsigned)BUF;
+            const int b1 = (t + 1) & 1, b2 = t & 1;
+            const bool s01 = t + 1 < nk || has_next;                 // phases 0 / 1 stage K-tile t + 1, or the next tile's K-tile 0
+            const int k01 = t + 1 < nk ? t + 1 : 0;
+            const bool s23 = t + 2 < nk || (t + 2 == nk && has_next);  // phases 2 / 3: K-tile t + 2, or the next tile's K-tile 0
+            const int k23 = t + 2 < nk ? t + 2 : 0;
+            // phase 0
+            DINO_READ_X(0, bo)
+            DINO_READ_W(0, bo)
+            if (s01) stage(1, k01, b1);
+            DINO_PHASE_END(0, 0)
+            // phase 1
+            DINO_READ_W(1, bo)
+            if (s01) stage(2, k01, b1);
+            DINO_PHASE_END(0, 1)
+            if (t + 2 == nk && has_next) {  // everything staged from here on belongs to the next output tile
                 int nm0, nn0;
                 tile_mn(chunk0 + tix + nb_x, nm0, nn0);
                 set_tile(nm0, nn0);
             }
-            const int pk = last ? 0 : kt + 2, pb = last ? 0 : (kt & 1);
-            DINO_MFMAS_P(xf1, wf1, DINO_SLOT_A(fetch, pb, pk, 0), DINO_SLOT_AB(fetch, pb, pk, 1, 0), DINO_SLOT_AB(fetch, pb, pk, 2, 1),
-                         DINO_SLOT_B(fetch, pb, pk, 2));
+            // phase 2
+            DINO_READ_X(1, bo)
+            if (s23) stage(0, k23, b2);
+            DINO_PHASE_END(1, 1)
+            // phase 3
+            DINO_READ_W(0, bo)
+            if (s23) {
+                stage(3, k23, b2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but X0, W1 of K-tile t + 2: K-tile t + 1 is in LDS
+            } else if (t + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            DINO_PHASE_END(1, 0)
         }
-        if (tix + nb_x < chunkn) {  // rest of the next tile's first K-tile: lands under the epilogue
-            piece(0, 0, 3);
-            piece(0, 0, 4);
-            piece(0, 0, 5);
-            piece(0, 0, 6);
-            piece(0, 0, 7);
-        }
-        DINO_WAIT_LGKM(0);
+        if (wx == 0) DINO_BAR()
 #undef DINO_DSR
-#undef DINO_LOAD_FRAGS
-#undef DINO_WAIT_LGKM
-#undef DINO_MFMAS
-#undef DINO_SLOT_A
-#undef DINO_SLOT_B
-#undef DINO_SLOT_AB
-#undef DINO_MFMAS_P
-#undef DINO_MFMA1
+#undef DINO_READ_X
+#undef DINO_READ_W
+#undef DINO_BAR
+#undef DINO_MMA
+#undef DINO_PHASE_END
 
         // ---- epilogue ----------------------------------------------------------------------------------------------
-        // acc[j][i][4g + e] = C[m, n] with  m = m0 + wx*128 + i*32 + (lane & 31)
-        //                                   n = n0 + ww*64 + j*32 + 8g + 4*(lane >> 5) + e
-        // LDS slice image: 64 rows x 128 B, 16-byte slot s of row r stored at slot s ^ (r & 7) (conflict-free reads).
-        // No block barrier is needed before writing the slices: they lie in stage 1, which nobody reads after the last
-        // K-tile barrier (all k-step-3 fragments were in registers before it).
+        // Each wave transposes its result through a private 8 KiB slice of buffer 1 (nobody reads buffer 1 after the last
+        // barrier above) and moves whole 128-byte lines.  LDS slice image: 64 rows x 128 B, 16-byte slot s of row r stored at
+        // slot s ^ (r & 7) (conflict-free reads).
         // `el` launders the lane id: without it LICM hoists ~40 loop-invariant epilogue addresses out of the persistent
         // tile loop, they stay live across the K loop and the kernel spills (fatal next to the asm-loaded fragments).
         int el = lane;
         asm volatile("" : "+v"(el));
-        const int er = el & 31, eh = el >> 5;
-        char* const ep = smem + STAGE + wid * 8192;
+        const int er = el & 15, eq = el >> 4;
+        char* const ep = smem + BUF + wid * 8192;
         const int mbase = m0 + wx * (32 * XREP);
-        const int ncol = n0 + ww * 64 + 4 * eh;
+        const int ncol = n0 + ww * 64 + 4 * eq;  // + 32 b + 16 j: this lane's four consecutive columns of block (b, j)
 
-        float4 bs[WREP][4];
+        float4 bs[2][2];
 #pragma unroll
-        for (int j = 0; j < WREP; ++j)
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                bs[j][g] = p.bias ? *(const float4*)(p.bias + ncol + j * 32 + 8 * g) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < 2; ++j)
+                bs[b][j] = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 
         if constexpr (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_SWIGLU) {
-            // 2-byte outputs: two passes of 64 rows x 64 columns (SwiGLU: x 32)
+            // 2-byte outputs: two passes (token halves) of 64 rows x 64 columns (SwiGLU: x 32)
             const float qs = (EPI == EPI_QKV && n0 < p.qcols) ? p.qscale : 1.0f;  // tiles never straddle q|k|v
-            constexpr int JN = EPI == EPI_SWIGLU ? 1 : WREP;
+            constexpr int BN_ = EPI == EPI_SWIGLU ? 1 : 2;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                for (int j = 0; j < JN; ++j)
+                for (int b = 0; b < BN_; ++b)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float bb[4] = {bs[j][g].x, bs[j][g].y, bs[j][g].z, bs[j][g].w};
-                        const float b2[4] = {bs[1][g].x, bs[1][g].y, bs[1][g].z, bs[1][g].w};
+                    for (int j = 0; j < 2; ++j) {
+                        const float bb[4] = {bs[b][j].x, bs[b][j].y, bs[b][j].z, bs[b][j].w};
+                        const float b2[4] = {bs[1][j].x, bs[1][j].y, bs[1][j].z, bs[1][j].w};
 #pragma unroll
-                        for (int ii = 0; ii < 2; ++ii) {
-                            const int i = 2 * q + ii;
-                            if (i >= XREP) continue;  // 192-row tiles: the second pass has one 32-row block
+                        for (int i = 0; i < 4; ++i) {
+                            if (q == 1 && i >= NI1) continue;  // 192-row tiles: the second pass has 32 rows
                             vec4 o;
 #ifndef DINO_GELU_SCALAR
                             if constexpr (EPI == EPI_GELU) {
                                 // Two columns per instruction: the bias add, x^2, the cubic, 1 + 2^t and the final product
                                 // run as v_pk_*_f32 (IEEE results identical to the scalar ops of gemm.hip, so both kernels
-                                // still agree bit for bit); v_exp / v_rcp / the f16 conversions stay per element.  The GELU
-                                // epilogue was ~24 % of this kernel: 9.5 VALU + 2 transcendental instructions per element.
+                                // still agree bit for bit); v_exp / v_rcp / the f16 conversions stay per element.
                                 typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                                 for (int e2 = 0; e2 < 2; ++e2) {
-                                    f32x2 v = {acc[j][i][4 * g + 2 * e2], acc[j][i][4 * g + 2 * e2 + 1]};
+                                    f32x2 v = {acc[q][b][i][j][2 * e2], acc[q][b][i][j][2 * e2 + 1]};
                                     v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
                                     asm volatile("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
                                     const f32x2 xr = {(float)(_Float16)v[0], (float)(_Float16)v[1]};
@@ -333,7 +323,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 #endif
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                float v = acc[j][i][4 * g + e] + bb[e];
+                                float v = acc[q][b][i][j][e] + bb[e];
                                 // keep the f32 sum a real register value: hipcc otherwise fuses "add, then round to f16"
                                 // into v_fma_mixlo_f16 for SOME unrolled instances (single rounding instead of the
                                 // reference's f32-then-f16 double rounding), which made results depend on the row's
@@ -344,8 +334,8 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                                     asm volatile("" : "+v"(vq));
                                     o[e] = E::from_f32(vq);
                                 } else if constexpr (EPI == EPI_SWIGLU) {
-                                    // W rows interleaved in 32-blocks: j = 0 holds x1[32q..], j = 1 holds x2[32q..]
-                                    const float h2 = acc[1][i][4 * g + e] + b2[e];
+                                    // W rows interleaved in 32-blocks: column half 0 holds x1[32 units], half 1 holds x2 of the same units
+                                    const float h2 = acc[q][1][i][j][e] + b2[e];
                                     float sg = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2;  // silu(x1) * x2
                                     asm volatile("" : "+v"(sg));
                                     o[e] = E::from_f32(sg);
@@ -361,9 +351,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                                     o[e] = E::from_f32((float)(_Float16)gl);
                                 }
                             }
-                            const int row = ii * 32 + er;
-                            const int slot = (4 * j + g) ^ (row & 7);
-                            *(vec4*)(ep + row * 128 + slot * 16 + eh * 8) = o;
+                            const int row = i * 16 + er;
+                            const int slot = (4 * b + 2 * j + (eq >> 1)) ^ (row & 7);  // 8 columns (16 B) per slot
+                            *(vec4*)(ep + row * 128 + slot * 16 + (eq & 1) * 8) = o;
                         }
                     }
                 __builtin_amdgcn_wave_barrier();
@@ -394,8 +384,8 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             // pos-embed rows) are issued before its LDS transposition and long before its first store.
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
-                const int j = ps >> 1, q = ps & 1;
-                const int nb = n0 + ww * 64 + j * 32 + (el & 7) * 4;
+                const int b = ps >> 1, q = ps & 1;
+                const int nb = n0 + ww * 64 + b * 32 + (el & 7) * 4;
                 float4 add[8];
                 if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
 #pragma unroll
@@ -411,19 +401,18 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
+                for (int j = 0; j < 2; ++j) {
                     float4 ls = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if constexpr (EPI == EPI_RESID) ls = *(const float4*)(p.aux + ncol + j * 32 + 8 * g);
-                    const float4 b4 = bs[j][g];
+                    if constexpr (EPI == EPI_RESID) ls = *(const float4*)(p.aux + ncol + b * 32 + j * 16);
+                    const float4 b4 = bs[b][j];
 #pragma unroll
-                    for (int ii = 0; ii < 2; ++ii) {
-                        const int i = 2 * q + ii;
-                        if (i >= XREP) continue;
-                        const int row = ii * 32 + er;
-                        const int slot = (2 * g + eh) ^ (row & 7);
+                    for (int i = 0; i < 4; ++i) {
+                        if (q == 1 && i >= NI1) continue;
+                        const int row = i * 16 + er;
+                        const int slot = (4 * j + eq) ^ (row & 7);  // 4 columns (16 B) per slot
                         *(float4*)(ep + row * 128 + slot * 16) =
-                            make_float4((acc[j][i][4 * g + 0] + b4.x) * ls.x, (acc[j][i][4 * g + 1] + b4.y) * ls.y,
-                                        (acc[j][i][4 * g + 2] + b4.z) * ls.z, (acc[j][i][4 * g + 3] + b4.w) * ls.w);
+                            make_float4((acc[q][b][i][j][0] + b4.x) * ls.x, (acc[q][b][i][j][1] + b4.y) * ls.y,
+                                        (acc[q][b][i][j][2] + b4.z) * ls.z, (acc[q][b][i][j][3] + b4.w) * ls.w);
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -437,8 +426,8 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                     if (m < M && (XREP == 4 || q * 64 + row < 32 * XREP)) {
                         size_t o;
                         if constexpr (EPI == EPI_PATCH) {
-                            const int b = m / p.P, pp = m - b * p.P;
-                            o = ((size_t)b * p.T + 1 + p.R + pp) * p.ldo + nb;
+                            const int bb_ = m / p.P, pp = m - bb_ * p.P;
+                            o = ((size_t)bb_ * p.T + 1 + p.R + pp) * p.ldo + nb;
                         } else {
                             o = (size_t)m * p.ldo + nb;
                         }

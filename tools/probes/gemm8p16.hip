@@ -1,0 +1,279 @@
+// gemm8p16.hip -- gemm8p.hip with the template's OWN MFMA shape, v_mfma_f32_16x16x32_f16 (gemm8p.hip used 32x32x16 like the product
+// kernel): 16 MFMAs per phase on a 64 x 32 quadrant = 4 x 2 blocks of 16 x 16, two k-steps of 32.  Same LDS image, same schedule.
+// gemm8p.hip -- the local guide's "256^2 8-phase template" (cdna_hip_programming.md, section 5) rebuilt from its description, as a
+// STANDALONE probe: C[M,N] f32 = A[M,K] f16 x W[N,K]^T f16 (both K-contiguous), plain f32 stores, one workgroup per tile.
+// Purpose: put a number for that schedule next to gemm2_kernel's on the same box, same random operands --
+// 4096^3 / 8192^3 (the guide quotes 1 320-1 340 / ~1 470 TFLOP/s) and the in-model FFN-in shape.
+//
+// Geometry (the template's): 256 x 256 x 64 tile, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64 = four 64 x 32 quadrants, 128 KiB
+// LDS = 2 K-tile buffers x 4 half-tiles of 16 KiB (A0, A1, B0, B1; half-tile = the 64 rows of every wave-row / the 32 columns of
+// every wave-column that ONE quadrant index uses).  One phase = one quadrant x all of K = 64: its fragment reads + two
+// global_load_lds (one half-tile of a later K-tile) in the MEM section, its MFMAs in the MMA section, a workgroup barrier after
+// each.  The two wave-rows (the two waves of every SIMD) run half a phase apart -- wave-row 1 takes one extra barrier up front --
+// so that one wave per SIMD is in its MMA section while its partner is in its MEM section.
+//
+// Schedule per K-tile t (phases j = 0..3; reads -> quadrant -> half-tile staged in that phase):
+//   j=0  A0(t) 8 reads + B0(t) 4 reads -> (a0,b0) -> stages A1(t+1)
+//   j=1  B1(t) 4 reads                 -> (a0,b1) -> stages B0(t+1)
+//   j=2  A1(t) 8 reads                 -> (a1,b1) -> stages A0(t+2)
+//   j=3  B0(t) 4 reads                 -> (a1,b0) -> stages B1(t+2), then s_waitcnt vmcnt(4): K-tile t+1 has landed
+// Hazards: a half-tile slot is re-staged two phases after its last read (every reader has retired the read and passed a barrier
+// in between); a K-tile is read one phase (two barriers for the other wave-row) after the counted wait that retires it.
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/gemm8p.hip -o /tmp/gemm8p && /tmp/gemm8p
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define LDS_AS __attribute__((address_space(3)))
+#define GLB_AS __attribute__((address_space(1)))
+
+#ifndef VARIANT
+#define VARIANT 0  // bit 0: no setprio; bit 1: lgkmcnt(0) BEFORE the barrier instead of after; bit 2: no stagger (both wave-rows in step)
+                   // timing-only (wrong results): bit 3 (8) no staging; bit 4 (16) no fragment reads; bit 5 (32) no MFMA
+#endif
+
+static __device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const GLB_AS void*)g, (LDS_AS void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void gemm8p(const _Float16* __restrict__ A, const _Float16* __restrict__ W, float* __restrict__ C,
+                                              int M, int N, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int ntn = N / 256, ntm = M / 256;
+    // XCD-aware tile order: block b runs on XCD b % 8; each XCD walks a contiguous chunk, 8 row panels swept column by column
+    const int nwg = ntn * ntm;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3, q = nwg >> 3, rr = nwg & 7;
+    const int lid = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+    constexpr int GM = 8;
+    const int g = lid / (GM * ntn), r0 = lid - g * (GM * ntn);
+    const int gm = ntm - g * GM < GM ? ntm - g * GM : GM;
+    const int tn = r0 / gm, tmi = r0 - tn * gm;
+    const int m0 = (g * GM + tmi) * 256, n0 = tn * 256;
+    const int nk = K / 64;
+
+    // ---- staging: half-tile h (0 A0, 1 A1, 2 B0, 3 B1) = 128 image rows x 128 B; this wave issues pieces 2 wid and 2 wid + 1 (8 rows each)
+    // image row r of an A half a: wave-row r >> 6, local row r & 63 -> tile row (r >> 6) * 128 + a * 64 + (r & 63)
+    // image row r of a  B half b: wave-col r >> 5, local col r & 31 -> tile col (r >> 5) * 64 + b * 32 + (r & 31)
+    unsigned src[4][2];  // byte offsets from A / W for K-tile 0
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int r = (2 * wid + p) * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ ((r >> 1) & 7);
+            const int grow = h < 2 ? m0 + (r >> 6) * 128 + h * 64 + (r & 63) : n0 + (r >> 5) * 64 + (h - 2) * 32 + (r & 31);
+            src[h][p] = (unsigned)grow * (unsigned)(K * 2) + ch * 16;
+        }
+    auto stage = [&](int h, int t) {  // h is a literal at every call site
+        if (VARIANT & 8) return;  // timing only: no staging
+        const char* base = (h < 2 ? (const char*)A : (const char*)W) + (size_t)t * 128;
+        char* dst = smem + ((t & 1) * 4 + h) * 16384 + (2 * wid) * 1024;
+        glds16(base + src[h][0], dst);
+        glds16(base + src[h][1], dst + 1024);
+    };
+
+    // ---- fragment addresses (16x16x32 MFMA: lane -> row lane & 15, k quarter lane >> 4; 16-byte chunk (4 ks + kq) ^ swizzle)
+    const int fr = lane & 15, kq = lane >> 4, sw = (fr >> 1) & 7;
+    const unsigned lds0 = (unsigned)(uintptr_t)(LDS_AS char*)smem;
+    unsigned xa[2], wa[2];  // per k-step of 32: byte address of this lane's fragment row in half-tile slot 0 of buffer 0
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned ch = (unsigned)(((ks * 4 + kq) ^ sw) << 4);
+        xa[ks] = lds0 + (unsigned)((wr * 64 + fr) * 128) + ch;  // A half image rows wr*64 .. +63 (four 16-row blocks at +2048 i)
+        wa[ks] = lds0 + (unsigned)((wc * 32 + fr) * 128) + ch;  // B half image rows wc*32 .. +31 (two 16-row blocks)
+    }
+
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x4 xf[4][2], wf[2][2];
+    if (VARIANT & 16)
+        for (int ks = 0; ks < 2; ++ks) {
+            for (int i = 0; i < 4; ++i) xf[i][ks] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+            wf[0][ks] = wf[1][ks] = u32x4{(unsigned)tid, 1u, 2u, 3u};
+        }
+
+#define DSR(DST, ADDR, OFF) \
+    if (!(VARIANT & 16)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))  /* 16: timing only, no reads */
+#define READ_A(SLOTOFF)                                              \
+    {                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {           \
+            const unsigned a__ = xa[ks] + (SLOTOFF);                 \
+            DSR(xf[0][ks], a__, 0);                                  \
+            DSR(xf[1][ks], a__, 2048);                               \
+            DSR(xf[2][ks], a__, 4096);                               \
+            DSR(xf[3][ks], a__, 6144);                               \
+        }                                                            \
+    }
+#define READ_B(SLOTOFF)                                              \
+    {                                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {           \
+            const unsigned a__ = wa[ks] + (SLOTOFF);                 \
+            DSR(wf[0][ks], a__, 0);                                  \
+            DSR(wf[1][ks], a__, 2048);                               \
+        }                                                            \
+    }
+#define BAR()                                   \
+    {                                           \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    }
+#define WAIT_LGKM0()                                            \
+    {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_sched_barrier(0);                      \
+    }
+#define MMA(QA, QB)                                                                                                      \
+    {                                                                                                                    \
+        if (!(VARIANT & 1)) __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            if (VARIANT & 32) { acc[QA][QB][i][j][0] += __builtin_bit_cast(float, xf[i][ks][0]) * __builtin_bit_cast(float, wf[j][ks][0]); continue; } \
+            acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[i][ks]),             \
+                                                                       __builtin_bit_cast(f16x8, wf[j][ks]), acc[QA][QB][i][j], 0, 0, 0); \
+        }                                                                                                                \
+        /* pin the MFMAs INSIDE this section: pure register ops otherwise sink below the barrier that ends it */         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[QA][QB][i][0]), "+v"(acc[QA][QB][i][1])); \
+        if (!(VARIANT & 1)) __builtin_amdgcn_s_setprio(0);                                                               \
+    }
+#define PHASE_END(QA, QB)                        \
+    if (VARIANT & 2) { WAIT_LGKM0(); BAR(); }    \
+    else { BAR(); WAIT_LGKM0(); }                \
+    MMA(QA, QB)                                  \
+    BAR()
+
+    // ---- prologue: K-tile 0 whole, A0 and B1 of K-tile 1 (what the steady state would have staged by now)
+    stage(0, 0); stage(2, 0); stage(1, 0); stage(3, 0);
+    if (nk > 1) { stage(0, 1); stage(3, 1); }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BAR();
+    if (!(VARIANT & 4) && wr == 1) BAR();  // wave-row 1 runs one barrier behind wave-row 0
+
+    for (int t = 0; t < nk; ++t) {
+        const unsigned bo = (unsigned)(t & 1) * 65536u;  // buffer of K-tile t; half-tile slots at +0 A0, +16384 A1, +32768 B0, +49152 B1
+        // j = 0
+        READ_A(bo + 0u);
+        READ_B(bo + 32768u);
+        if (t + 1 < nk) stage(1, t + 1);
+        PHASE_END(0, 0)
+        // j = 1
+        READ_B(bo + 49152u);
+        if (t + 1 < nk) stage(2, t + 1);
+        PHASE_END(0, 1)
+        // j = 2
+        READ_A(bo + 16384u);
+        if (t + 2 < nk) stage(0, t + 2);
+        PHASE_END(1, 1)
+        // j = 3
+        READ_B(bo + 32768u);
+        if (t + 2 < nk) {
+            stage(3, t + 2);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but A0(t+2), B1(t+2): K-tile t+1 is in LDS
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PHASE_END(1, 0)
+    }
+    if (!(VARIANT & 4) && wr == 0) BAR();
+
+    // ---- epilogue: plain f32 stores.  acc[a][b][i][j][e] = C[m0 + wr*128 + a*64 + i*16 + 4*kq + e][n0 + wc*64 + b*32 + j*16 + fr]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int m = m0 + wr * 128 + a * 64 + i * 16 + 4 * kq + e;
+                        C[(size_t)m * N + n0 + wc * 64 + b * 32 + j * 16 + fr] = acc[a][b][i][j][e];
+                    }
+}
+
+// reference: one thread per sampled output
+__global__ void ref_kernel(const _Float16* A, const _Float16* W, const int* ms, const int* ns, float* out, int K, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += (float)A[(size_t)ms[i] * K + k] * (float)W[(size_t)ns[i] * K + k];
+    out[i] = s;
+}
+
+__global__ void fill(_Float16* p, size_t n, unsigned seed) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = (_Float16)((float)(x & 0xffffff) * (2.0f / 16777216.0f) - 1.0f);
+    }
+}
+
+static void run(int M, int N, int K, int iters) {
+    _Float16 *A, *W;
+    float* C;
+    hipMalloc(&A, (size_t)M * K * 2); hipMalloc(&W, (size_t)N * K * 2); hipMalloc(&C, (size_t)M * N * 4);
+    fill<<<1024, 256>>>(A, (size_t)M * K, 1u); fill<<<1024, 256>>>(W, (size_t)N * K, 2u);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm8p), hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    const dim3 grid((M / 256) * (N / 256)), block(512);
+    hipLaunchKernelGGL(gemm8p, grid, block, 131072, 0, A, W, C, M, N, K);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(e)); exit(1); }
+    // refcheck on 4096 sampled outputs (transposes / wrong quadrants / races show up as O(1) errors)
+    const int ns_ = 4096;
+    std::vector<int> hm(ns_), hn(ns_);
+    for (int i = 0; i < ns_; ++i) { hm[i] = (int)(((unsigned)rand() * 2654435761u) % (unsigned)M); hn[i] = (int)(((unsigned)rand() * 40503u + 17) % (unsigned)N); }
+    int *dm, *dn; float* dr;
+    hipMalloc(&dm, ns_ * 4); hipMalloc(&dn, ns_ * 4); hipMalloc(&dr, ns_ * 4);
+    hipMemcpy(dm, hm.data(), ns_ * 4, hipMemcpyHostToDevice); hipMemcpy(dn, hn.data(), ns_ * 4, hipMemcpyHostToDevice);
+    ref_kernel<<<(ns_ + 255) / 256, 256>>>(A, W, dm, dn, dr, K, ns_);
+    std::vector<float> href(ns_), hc(ns_);
+    hipMemcpy(href.data(), dr, ns_ * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int i = 0; i < ns_; ++i) {
+        float v;
+        hipMemcpy(&v, C + (size_t)hm[i] * N + hn[i], 4, hipMemcpyDeviceToHost);
+        worst = std::fmax(worst, std::fabs((double)v - href[i]));
+    }
+    // warm up ~100 ms, then time
+    for (int i = 0; i < 200; ++i) hipLaunchKernelGGL(gemm8p, grid, block, 131072, 0, A, W, C, M, N, K);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(gemm8p, grid, block, 131072, 0, A, W, C, M, N, K);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    ms /= iters;
+    printf("gemm8p16 v%d M=%d N=%d K=%d: %.4f ms  %.1f TFLOP/s  (%.3f us per K-tile-round)  refcheck max|d| = %.3g %s\n", VARIANT, M, N, K, ms,
+           2.0 * M * N * K / ms / 1e9, ms * 1e3 / ((double)(K / 64) * (((M / 256) * (N / 256) + 255) / 256)), worst,
+           worst < 2e-2 * std::sqrt((double)K / 1024) ? "OK" : "MISMATCH");
+    hipFree(A); hipFree(W); hipFree(C); hipFree(dm); hipFree(dn); hipFree(dr);
+}
+
+int main() {
+    run(256, 256, 128, 1);
+    run(512, 768, 1024, 10);
+    run(4096, 4096, 4096, 50);
+    run(8192, 8192, 8192, 10);
+    run(43776, 4096, 1024, 50);  // FFN-in shape rounded down to whole 256-row tiles
+    return 0;
+}
