@@ -13,9 +13,12 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define REP 128
 
-template <int MODE, int DEP>
+template <int MODE, int DEP, int SHAPE = 32>
 __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed) {
     f16v acc[4];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v acc4[4][2];
+    for (int c = 0; c < 4; ++c) acc4[c][0] = acc4[c][1] = f4v{seed, 1.f, 2.f, 3.f};
     float r[32];
     for (int c = 0; c < 4; ++c)
         for (int i = 0; i < 16; ++i) acc[c][i] = seed * i;
@@ -29,12 +32,21 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[c]) : "v"(a));
+                for (int s = 0; s < 4; ++s) {
+                    if (SHAPE == 32) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[c]) : "v"(a));
+                    else {  // the same flops as two 16x16x32 on two 4-register accumulators (8 chains of 4 dependent MFMAs per tile)
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(acc4[c][0]) : "v"(a));
+                        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %1, %0" : "+v"(acc4[c][1]) : "v"(a));
+                    }
+                }
         }
         if (MODE != 1) {
             if (DEP) {  // the VALU phase reads the accumulators (as the softmax does): forces the wave to wait for its MFMAs
 #pragma unroll
-                for (int c = 0; c < 4; ++c) asm volatile("s_nop 7\n s_nop 7\n v_add_f32 %0, %0, %1" : "+v"(r[c]) : "v"(acc[c][0]));
+                for (int c = 0; c < 4; ++c) {
+                    if (SHAPE == 32) asm volatile("s_nop 7\n s_nop 7\n v_add_f32 %0, %0, %1" : "+v"(r[c]) : "v"(acc[c][0]));
+                    else asm volatile("s_nop 7\n s_nop 7\n v_add_f32 %0, %0, %1" : "+v"(r[c]) : "v"(acc4[c][1][0]));
+                }
             }
 #pragma unroll
             for (int i = 0; i < 32; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
@@ -50,19 +62,19 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) s += r[i];
-    for (int c = 0; c < 4; ++c) s += acc[c][3];
+    for (int c = 0; c < 4; ++c) s += acc[c][3] + acc4[c][0][1] + acc4[c][1][2];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) { cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2] = t0; cyc[(blockIdx.x * 16 + (threadIdx.x >> 6)) * 2 + 1] = t1; }
 }
 
-template <int MODE, int DEP>
+template <int MODE, int DEP, int SHAPE = 32>
 static void run(const char* name) {
     float* out; long long* cyc;
     hipMalloc(&out, 1024 * 4 * 256); hipMalloc(&cyc, 8 * 256 * 32);
     printf("%-34s", name);
     for (int wps : {1, 2, 3, 4}) {
-        hipLaunchKernelGGL((k<MODE, DEP>), dim3(256), dim3(256 * wps), 0, 0, out, cyc, 0.5f);
-        hipLaunchKernelGGL((k<MODE, DEP>), dim3(256), dim3(256 * wps), 0, 0, out, cyc, 0.5f);
+        hipLaunchKernelGGL((k<MODE, DEP, SHAPE>), dim3(256), dim3(256 * wps), 0, 0, out, cyc, 0.5f);
+        hipLaunchKernelGGL((k<MODE, DEP, SHAPE>), dim3(256), dim3(256 * wps), 0, 0, out, cyc, 0.5f);
         hipDeviceSynchronize();
         std::vector<long long> c(256 * 32); hipMemcpy(c.data(), cyc, 8 * 256 * 32, hipMemcpyDeviceToHost);
         double avg = 0;
@@ -82,5 +94,8 @@ int main() {
     run<2, 0>("112 VALU only (32 exp)");
     run<0, 0>("both, VALU independent of MFMA");
     run<0, 1>("both, VALU reads the accumulators");
+    run<1, 0, 16>("32 MFMA 16x16x32 only");
+    run<0, 0, 16>("16x16x32: both, VALU independent");
+    run<0, 1, 16>("16x16x32: both, VALU reads acc");
     return 0;
 }
