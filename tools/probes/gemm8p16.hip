@@ -103,6 +103,7 @@ __global__ __launch_bounds__(512) void gemm8p(const _Float16* __restrict__ A, co
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     u32x4 xf[4][2], wf[2][2];
+    u32x4 xg[2][2], wg[2][2];  // VARIANT & 64: second token half's blocks 0-1 / column half 1 (balanced fragment reads)
     if (VARIANT & 16)
         for (int ks = 0; ks < 2; ++ks) {
             for (int i = 0; i < 4; ++i) xf[i][ks] = u32x4{(unsigned)tid, 1u, 2u, 3u};
@@ -168,6 +169,70 @@ __global__ __launch_bounds__(512) void gemm8p(const _Float16* __restrict__ A, co
     BAR();
     if (!(VARIANT & 4) && wr == 1) BAR();  // wave-row 1 runs one barrier behind wave-row 0
 
+    if (VARIANT & 64) {
+        // Balanced fragment reads: 8 / 8 / 4 / 4 per phase instead of 12 / 4 / 8 / 4, 24 per K-tile instead of 28 (W0 stays in
+        // registers, nothing is read twice).  X0 blocks 0-1 of K-tile t+1 are read in phase 3 of K-tile t: the counted wait that
+        // retires them moves to phase 2 (vmcnt(8): everything but X1(t+1), W0(t+1), X0(t+2) -- i.e. X0(t+1), W1(t+1) landed, they
+        // were staged a whole K-tile ago).
+#define MMA2(QA, QB, X0_, X1_, X2_, X3_, W_)                                                                              \
+    {                                                                                                                    \
+        if (!(VARIANT & 1)) __builtin_amdgcn_s_setprio(1);                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                               \
+            const u32x4 xs__[4] = {X0_[ks], X1_[ks], X2_[ks], X3_[ks]};                                                  \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                \
+                acc[QA][QB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xs__[i]),           \
+                                                                           __builtin_bit_cast(f16x8, W_[j][ks]), acc[QA][QB][i][j], 0, 0, 0); \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(acc[QA][QB][i][0]), "+v"(acc[QA][QB][i][1])); \
+        if (!(VARIANT & 1)) __builtin_amdgcn_s_setprio(0);                                                               \
+    }
+#define PHASE_END2(QA, QB, X0_, X1_, X2_, X3_, W_) \
+    BAR(); WAIT_LGKM0();                           \
+    MMA2(QA, QB, X0_, X1_, X2_, X3_, W_)           \
+    BAR()
+#define RDX(DST, A_, I_, BO)                                                        \
+    {                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                          \
+            const unsigned a__ = xa[ks] + (BO) + (A_) * 16384u;                     \
+            DSR(DST[ks], a__, (I_) * 2048);                                         \
+        }                                                                           \
+    }
+#define RDW(DST, B_, BO)                                                            \
+    {                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                          \
+            const unsigned a__ = wa[ks] + (BO) + 32768u + (B_) * 16384u;            \
+            DSR(DST[0][ks], a__, 0);                                                \
+            DSR(DST[1][ks], a__, 2048);                                             \
+        }                                                                           \
+    }
+        RDX(xf[0], 0, 0, 0u) RDX(xf[1], 0, 1, 0u)  // X0(0) blocks 0-1: what phase 3 of K-tile -1 would have read
+        for (int t = 0; t < nk; ++t) {
+            const unsigned bo = (unsigned)(t & 1) * 65536u, bn = (unsigned)((t + 1) & 1) * 65536u;
+            // phase 0
+            RDX(xf[2], 0, 2, bo) RDX(xf[3], 0, 3, bo) RDW(wf, 0, bo)
+            if (t + 1 < nk) stage(1, t + 1);
+            PHASE_END2(0, 0, xf[0], xf[1], xf[2], xf[3], wf)
+            // phase 1
+            RDW(wg, 1, bo) RDX(xg[0], 1, 0, bo) RDX(xg[1], 1, 1, bo)
+            if (t + 1 < nk) stage(2, t + 1);
+            PHASE_END2(0, 1, xf[0], xf[1], xf[2], xf[3], wg)
+            // phase 2
+            RDX(xf[2], 1, 2, bo) RDX(xf[3], 1, 3, bo)
+            if (t + 2 < nk) { stage(0, t + 2); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PHASE_END2(1, 1, xg[0], xg[1], xf[2], xf[3], wg)
+            // phase 3
+            if (t + 1 < nk) { RDX(xf[0], 0, 0, bn) RDX(xf[1], 0, 1, bn) }
+            if (t + 2 < nk) {
+                stage(3, t + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PHASE_END2(1, 0, xg[0], xg[1], xf[2], xf[3], wf)
+        }
+    } else
     for (int t = 0; t < nk; ++t) {
         const unsigned bo = (unsigned)(t & 1) * 65536u;  // buffer of K-tile t; half-tile slots at +0 A0, +16384 A1, +32768 B0, +49152 B1
         // j = 0
