@@ -262,10 +262,12 @@ def test_convert_weight_dequant(api, pkg, tname):
 
 
 @pytest.mark.parametrize("epi", ["plain", "resid", "qkv", "gelu"])
-@pytest.mark.parametrize("M,N,K", [(20000, 1024, 512), (43968, 1024, 1024), (9000, 3072, 256)])
+@pytest.mark.parametrize("M,N,K", [(20000, 1024, 512), (43968, 1024, 1024), (9000, 3072, 256), (70000, 256, 128), (33000, 512, 128)])
 def test_gemm_persistent_multi_tile(api, epi, M, N, K):
-    """The 256x256 persistent kernel with more tiles than CUs: every block walks several tiles, prefetching the next
-    tile's first K-tile under its epilogue.  Whole output checked (a stale-LDS race shows up as a few wrong tiles)."""
+    """The 256x256 persistent kernel with more tiles than CUs: every block walks several tiles, staging the next tile's
+    first K-tile during its last phases and under its epilogue.  Whole output checked (a stale-LDS race shows up as a few
+    wrong tiles).  K = 128 is the shortest K loop the kernel takes (two K-tiles: the cross-tile staging starts in the
+    tile's very first phases)."""
     rng = np.random.default_rng(M + K)
     A = _round(rng.standard_normal((M, K)), F16)
     W = _round(rng.standard_normal((N, K)) * 0.05 + np.linspace(-0.02, 0.03, N)[:, None], F16)
