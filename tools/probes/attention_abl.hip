@@ -83,6 +83,27 @@ static __device__ __forceinline__ f32x16 mfma32_c(V8 a, V8 b, const f32x16& c) {
     return d;
 }
 
+// DINO_ATT_FAKE16 (timing only, WRONG results): every 32x32x16 MFMA of attention_kernel replaced by the same FLOPs as two
+// 16x16x32 MFMAs on two 4-register pieces of its accumulator -- does the MFMA shape change how the matrix work interferes with
+// the kernel's data movement, as it does in the GEMM?
+#ifndef DINO_ATT_FAKE16
+#define DINO_ATT_FAKE16 0
+#endif
+template <typename E, typename V8>
+static __device__ __forceinline__ f32x16 fake16(V8 a, V8 b, f32x16 c) {
+    f32x4 c0 = {c[0], c[1], c[2], c[3]}, c1 = {c[4], c[5], c[6], c[7]};
+    if constexpr (__is_same(V8, f16x8)) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+    } else {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+    }
+    c[0] = c0[0]; c[1] = c0[1]; c[2] = c0[2]; c[3] = c0[3];
+    c[4] = c1[0]; c[5] = c1[1]; c[6] = c1[2]; c[7] = c1[3];
+    return c;
+}
+
 // hipcc's hazard recogniser pads an MFMA result -> VALU read with the required wait states only when it can see the reader;
 // the asm v_max3 below is opaque to it, so reading fresh accumulators raced with the matrix pipeline (nondeterministic
 // scores, found by the batch-permutation test).  19 wait states cover a 16-pass MFMA; tied operands order the block after
@@ -266,6 +287,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
                         s[u][kb][ks] += (float)kf[0] * (float)qf[u][ks][1];
                         continue;
                     }
+                    if (DINO_ATT_FAKE16) { s[u][kb] = fake16<E>(kf, qf[u][ks], ks == 0 ? negm[u] : s[u][kb]); continue; }
                     if (ks == 0) s[u][kb] = mfma32_c(kf, qf[u][0], negm[u]);  // D != C: no copy of the 16 -m_run registers per chain
                     else s[u][kb] = E::mfma32(kf, qf[u][ks], s[u][kb]);
                 }
@@ -348,7 +370,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #pragma unroll
                 for (int u = 0; u < QB; ++u) {
                     if (DINO_ATT_ABL & 32) { o[u][db][t] += (float)vf[0] * (float)pf[u][1]; continue; }
-                    o[u][db] = E::mfma32(vf, pf[u], o[u][db]);
+                    o[u][db] = DINO_ATT_FAKE16 ? fake16<E>(vf, pf[u], o[u][db]) : E::mfma32(vf, pf[u], o[u][db]);
                 }
             }
         }
