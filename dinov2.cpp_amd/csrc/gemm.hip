@@ -4,7 +4,7 @@
 // (/root/reference/dinov2.cpp:471-474 qkv, :546-551 out-proj + :708-714 LayerScale/residual, :561-567 fc1+GELU,
 //  :570-573 fc2 + :744-749, :582-605 weights_in+SwiGLU, :608-611 weights_out, :636-671 patch-embed + pos-embed).
 // Numerics contract = ggml CPU mul_mat with F16 weights: activations rounded to the weight type, products and
-// accumulation in f32 (v_mfma_f32_32x32x16_{f16,bf16}).
+// accumulation in f32 (v_mfma_f32_16x16x32_{f16,bf16}).
 //
 // Structure (MI355X-first, not a CUDA tiling):
 //   * C[M,N] = A[M,K] * W[N,K]^T; both operands are K-contiguous, so A and B fragments are plain 16-byte
@@ -38,9 +38,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     constexpr int ROWB = BK * 2;  // bytes per LDS row
     constexpr int STAGE = (BM + BN) * ROWB;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
-    constexpr int MREP = WTM / 32, NREP = WTN / 32;
+    constexpr int MREP = WTM / 16, NREP = WTN / 16;  // 16 x 16 accumulator blocks of the wave tile (MFMA 16x16x32)
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // glds wave-instructions per wave per tile
-    static_assert(NREP == 2, "SwiGLU pairing and the register budget assume a 64-wide wave tile");
+    static_assert(NREP == 4, "SwiGLU pairing and the register budget assume a 64-wide wave tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
 
@@ -91,19 +91,17 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 
     // ---- fragment read offsets ----
     const int wm = wid / WN, wn = wid % WN;
-    const int fr = lane & 31;             // row within a 32-row MFMA block
-    const int fh = lane >> 5;             // which 8-wide k half of a 16-wide k step
-    const int sw = (fr >> 1) & 7;         // swizzle term (block bases are multiples of 32 rows)
+    const int fr = lane & 15;             // row within a 16-row MFMA block
+    const int fh = lane >> 4;             // which 8-wide k quarter of a 32-wide k step
+    const int sw = (fr >> 1) & 7;         // swizzle term (block bases are multiples of 16 rows)
     const int aoff = (wm * WTM + fr) * ROWB;
     const int boff = BM * ROWB + (wn * WTN + fr) * ROWB;
 
-    f32x16 acc[MREP][NREP];
+    f32x4 acc[MREP][NREP];
 #pragma unroll
     for (int i = 0; i < MREP; ++i)
 #pragma unroll
-        for (int j = 0; j < NREP; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // NST-stage LDS ring, tiles kt+1 .. kt+NST-1 in flight while tile kt is multiplied: with few workgroups per CU (small M)
     // nothing else hides the global -> LDS latency.  One barrier per K tile: (a) every wave's loads of tile kt have landed
@@ -128,25 +126,25 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         nbuf = buf;  // the buffer just consumed is the next to be refilled
         buf = buf + 1 == NST ? 0 : buf + 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int ch = ((ks * 2 + fh) ^ sw) << 4;
+        for (int ks = 0; ks < 2; ++ks) {  // two k-steps of 32: the K order of gemm2.hip, so both kernels give a row the same bits
+            const int ch = ((ks * 4 + fh) ^ sw) << 4;
             vec8 af[MREP], bf[NREP];
 #pragma unroll
-            for (int i = 0; i < MREP; ++i) af[i] = *(const vec8*)(s + aoff + i * 32 * ROWB + ch);
+            for (int i = 0; i < MREP; ++i) af[i] = *(const vec8*)(s + aoff + i * 16 * ROWB + ch);
 #pragma unroll
-            for (int j = 0; j < NREP; ++j) bf[j] = *(const vec8*)(s + boff + j * 32 * ROWB + ch);
+            for (int j = 0; j < NREP; ++j) bf[j] = *(const vec8*)(s + boff + j * 16 * ROWB + ch);
 #pragma unroll
             for (int i = 0; i < MREP; ++i)
 #pragma unroll
                 for (int j = 0; j < NREP; ++j) {
-                    acc[i][j] = E::mfma32(af[i], bf[j], acc[i][j]);
+                    acc[i][j] = E::mfma16(bf[j], af[i], acc[i][j]);  // operand swap (as gemm2.hip): a lane owns one row, four columns
                 }
         }
     }
 
     if constexpr (KS == 2) {
         // group 1 -> LDS -> group 0: element (wave, accumulator register q) of lane l at float index (wave * NQ + q) * 64 + l
-        constexpr int NQ = MREP * NREP * 16;
+        constexpr int NQ = MREP * NREP * 4;
         static_assert(NW * NQ * 256 <= NST * STAGE, "the hand-over buffer reuses group 0's ring");
         float* const xch = (float*)smem_all + (size_t)wid * NQ * 64 + lane;
         __syncthreads();  // every wave has finished its last fragment reads: group 0's ring is free
@@ -156,7 +154,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) xch[((i * NREP + j) * 16 + r) * 64] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) xch[((i * NREP + j) * 4 + r) * 64] = acc[i][j][r];
         }
         __syncthreads();
         if (grp == 1) return;
@@ -165,82 +163,113 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < NREP; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * NREP + j) * 16 + r) * 64];  // acc_lo + acc_hi
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += xch[((i * NREP + j) * 4 + r) * 64];  // acc_lo + acc_hi
     }
 
     // ---- epilogue: acc[i][j][r] is C[row, col] with
-    //      row = m0 + wm*WTM + i*32 + (r&3) + 8*(r>>2) + 4*(lane>>5),  col = n0 + wn*WTN + j*32 + (lane&31)
-    const int colb = n0 + wn * WTN + fr;
-    const int rowb = m0 + wm * WTM + 4 * fh;
+    //      row = m0 + wm*WTM + i*16 + (lane&15),  col = n0 + wn*WTN + j*16 + 4*(lane>>4) + r   (r = 0..3: four consecutive columns)
+    // Edge-guarded per element in M and N (N = 1000-style shapes take the scalar path for their last columns).
+    const int colb = n0 + wn * WTN + 4 * fh;
+    const int rowb = m0 + wm * WTM + fr;
 
     if constexpr (EPI == EPI_SWIGLU) {
-        // W rows interleaved in 32-blocks: n-block 2q holds x1[32q..], n-block 2q+1 holds x2[32q..]
-        const int c1 = colb, c2 = colb + 32;
-        const float b1 = (p.bias && c1 < N) ? p.bias[c1] : 0.f;
-        const float b2 = (p.bias && c2 < N) ? p.bias[c2] : 0.f;
-        const int j = ((n0 + wn * WTN) >> 6) * 32 + fr;  // hidden unit index
+        // W rows interleaved in 32-blocks: columns 0..31 of the wave's 64 hold x1[32 units], columns 32..63 x2 of the same units
         T* out = (T*)p.out;
 #pragma unroll
-        for (int i = 0; i < MREP; ++i)
+        for (int jh = 0; jh < 2; ++jh)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < M && c2 < N) {
-                    const float h1 = acc[i][0][r] + b1, h2 = acc[i][1][r] + b2;
-                    float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1)) * h2;  // silu(x1) * x2, dinov2.cpp:605
-                    asm volatile("" : "+v"(sl));
-                    out[(size_t)row * p.ldo + j] = E::from_f32(sl);
+            for (int r = 0; r < 4; ++r) {
+                const int c1 = colb + jh * 16 + r, c2 = c1 + 32;
+                const float b1 = (p.bias && c1 < N) ? p.bias[c1] : 0.f;
+                const float b2 = (p.bias && c2 < N) ? p.bias[c2] : 0.f;
+                const int hu = ((n0 + wn * WTN) >> 6) * 32 + jh * 16 + 4 * fh + r;  // hidden unit index
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    const int row = rowb + i * 16;
+                    if (row < M && c2 < N) {
+                        const float h1 = acc[i][jh][r] + b1, h2 = acc[i][jh + 2][r] + b2;
+                        float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1)) * h2;  // silu(x1) * x2, dinov2.cpp:605
+                        asm volatile("" : "+v"(sl));
+                        out[(size_t)row * p.ldo + hu] = E::from_f32(sl);
+                    }
                 }
             }
         return;
     } else {
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
-            const int col = colb + jn * 32;
-            if (col >= N) continue;
-            const float bias = p.bias ? p.bias[col] : 0.f;
-            float auxv = 0.f;
-            if constexpr (EPI == EPI_RESID) auxv = p.aux[col];
-            if constexpr (EPI == EPI_QKV) auxv = col < p.qcols ? p.qscale : 1.0f;
+            const int col0 = colb + jn * 16;
+            if (col0 >= N) continue;
+            const bool full = col0 + 3 < N && (p.ldo & 3) == 0;  // the lane's four columns exist and rows are 16-byte aligned: vector path
+            float bias[4], auxv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = col0 + r < N ? col0 + r : N - 1;
+                bias[r] = p.bias ? p.bias[col] : 0.f;
+                auxv[r] = 0.f;
+                if constexpr (EPI == EPI_RESID) auxv[r] = p.aux[col];
+                if constexpr (EPI == EPI_QKV) auxv[r] = col < p.qcols ? p.qscale : 1.0f;
+            }
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
-                float xin[16];
-                if constexpr (EPI == EPI_RESID) {
-                    // issue all 16 residual loads (rows clamped, unconditional) before the first dependent store
+                const int row = rowb + i * 16;
+                if (row >= M) continue;
+                float v[4];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
-                        row = row < M ? row : M - 1;
-                        xin[r] = ((const float*)p.out)[(size_t)row * p.ldo + col];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][jn][r] + bias[r];
+                    asm volatile("" : "+v"(v[r]));  // f32 value first, then any f16 rounding (no v_fma_mix fusion: gemm2.hip)
                 }
+                if constexpr (EPI == EPI_PATCH) {
+                    const int b = row / p.P, pp = row - b * p.P;
+                    float* x = (float*)p.out + ((size_t)b * p.T + 1 + p.R + pp) * p.ldo;
+                    const float* pe = p.aux + (size_t)(1 + pp) * N;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rowb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row >= M) continue;
-                    float v = acc[i][jn][r] + bias;
-                    asm volatile("" : "+v"(v));  // f32 value first, then any f16 rounding (no v_fma_mix fusion: gemm2.hip)
-                    if constexpr (EPI == EPI_PATCH) {
-                        const int b = row / p.P, pp = row - b * p.P;
-                        float* x = (float*)p.out;
-                        x[((size_t)b * p.T + 1 + p.R + pp) * p.ldo + col] = v + p.aux[(size_t)(1 + pp) * N + col];
-                    } else if constexpr (EPI == EPI_QKV) {
-                        float vq = v * auxv;
-                        asm volatile("" : "+v"(vq));
-                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32(vq);
-                    } else if constexpr (EPI == EPI_RESID) {
-                        ((float*)p.out)[(size_t)row * p.ldo + col] = v * auxv + xin[r];
-                    } else if constexpr (EPI == EPI_GELU) {
-                        // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))).  EXACTLY the expression of
-                        // gemm2.hip (same constants, same operation order; the x <= -10 / x >= 10 branches fall out of it):
-                        // a token must get the same bits from either kernel, whatever batch it arrives in.
-                        const float xr = (float)(_Float16)v;
-                        const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
-                        float g = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-                        asm volatile("" : "+v"(g));
-                        ((T*)p.out)[(size_t)row * p.ldo + col] = E::from_f32((float)(_Float16)g);
-                    } else {  // EPI_PLAIN_F32
-                        ((float*)p.out)[(size_t)row * p.ldo + col] = v;
+                    for (int r = 0; r < 4; ++r)
+                        if (col0 + r < N) x[col0 + r] = v[r] + pe[col0 + r];
+                } else if constexpr (EPI == EPI_RESID) {
+                    float* x = (float*)p.out + (size_t)row * p.ldo;
+                    if (full) {
+                        const float4 xin = *(const float4*)(x + col0);
+                        *(float4*)(x + col0) = make_float4(v[0] * auxv[0] + xin.x, v[1] * auxv[1] + xin.y, v[2] * auxv[2] + xin.z, v[3] * auxv[3] + xin.w);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col0 + r < N) x[col0 + r] = v[r] * auxv[r] + x[col0 + r];
+                    }
+                } else if constexpr (EPI == EPI_PLAIN_F32) {
+                    float* x = (float*)p.out + (size_t)row * p.ldo;
+                    if (full) *(float4*)(x + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col0 + r < N) x[col0 + r] = v[r];
+                    }
+                } else {  // EPI_QKV, EPI_GELU: 2-byte outputs
+                    typename E::vec4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if constexpr (EPI == EPI_QKV) {
+                            float vq = v[r] * auxv[r];
+                            asm volatile("" : "+v"(vq));
+                            o[r] = E::from_f32(vq);
+                        } else {
+                            // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))).  EXACTLY the expression of
+                            // gemm2.hip (same constants, same operation order; the x <= -10 / x >= 10 branches fall out of it):
+                            // a token must get the same bits from either kernel, whatever batch it arrives in.
+                            const float xr = (float)(_Float16)v[r];
+                            const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
+                            float g = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+                            asm volatile("" : "+v"(g));
+                            o[r] = E::from_f32((float)(_Float16)g);
+                        }
+                    }
+                    T* y = (T*)p.out + (size_t)row * p.ldo;
+                    if (full) *(typename E::vec4*)(y + col0) = o;
+                    else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (col0 + r < N) y[col0 + r] = o[r];
                     }
                 }
             }
