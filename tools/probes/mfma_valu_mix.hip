@@ -28,6 +28,18 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < REP; ++it) {
+        if (MODE == 3) {  // the same 16 MFMA 32x32x16 + 112 VALU, interleaved in program order: one MFMA, then 7 VALU (2 exp, 4 add, 1 cvt)
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[m & 3]) : "v"(a));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(r[2 * m]));
+                asm volatile("v_exp_f32 %0, %0" : "+v"(r[2 * m + 1]));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[(4 * m + q) & 31]) : "v"(r[(4 * m + q + 1) & 31]));
+                asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(r[(2 * m) & 31]) : "v"(r[(2 * m + 1) & 31]));
+            }
+            continue;
+        }
         if (MODE != 2) {
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -59,6 +71,7 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed
         }
     }
     const long long t1 = __builtin_readcyclecounter();
+    (void)0;
     float s = 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) s += r[i];
@@ -94,6 +107,7 @@ int main() {
     run<2, 0>("112 VALU only (32 exp)");
     run<0, 0>("both, VALU independent of MFMA");
     run<0, 1>("both, VALU reads the accumulators");
+    run<3, 0>("interleaved in ONE instruction stream");
     run<1, 0, 16>("32 MFMA 16x16x32 only");
     run<0, 0, 16>("16x16x32: both, VALU independent");
     run<0, 1, 16>("16x16x32: both, VALU reads acc");
