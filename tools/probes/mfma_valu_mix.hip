@@ -28,6 +28,26 @@ __global__ __launch_bounds__(1024) void k(float* out, long long* cyc, float seed
     __syncthreads();
     const long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < REP; ++it) {
+        if (MODE == 4) {  // barrier-staggered ping-pong: one wave of each SIMD in its MFMA section while its partner is in its VALU section
+            if (it == 0 && (threadIdx.x >> 8) == 1) __builtin_amdgcn_s_barrier();  // waves 4-7 (the SIMD partners) run one section behind
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+v"(acc[c]) : "v"(a));
+            asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int i = 0; i < 32; ++i) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int i = 0; i < 32; ++i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(r[(i + 1) & 31]));
+#pragma unroll
+            for (int i = 0; i < 32; i += 2) asm volatile("v_cvt_pk_f16_f32 %0, %0, %1" : "+v"(r[i]) : "v"(r[i + 1]));
+            __builtin_amdgcn_s_barrier();
+            if (it == REP - 1 && (threadIdx.x >> 8) == 0) __builtin_amdgcn_s_barrier();
+            continue;
+        }
         if (MODE == 3) {  // the same 16 MFMA 32x32x16 + 112 VALU, interleaved in program order: one MFMA, then 7 VALU (2 exp, 4 add, 1 cvt)
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
@@ -108,6 +128,7 @@ int main() {
     run<0, 0>("both, VALU independent of MFMA");
     run<0, 1>("both, VALU reads the accumulators");
     run<3, 0>("interleaved in ONE instruction stream");
+    run<4, 0>("barrier-staggered ping-pong (wps=2 only)");
     run<1, 0, 16>("32 MFMA 16x16x32 only");
     run<0, 0, 16>("16x16x32: both, VALU independent");
     run<0, 1, 16>("16x16x32: both, VALU reads acc");
