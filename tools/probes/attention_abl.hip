@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #pragma unroll
         for (int u = 0; u < QB; ++u) {
             mfma_settle(s[u]);
-            const float mx = (DINO_ATT_ABL & (64 | 128)) ? s[u][0][3] : max_halves(max32(s[u]));  // 128: no tile maximum only  // tile maximum relative to m_run
+            const float mx = (DINO_ATT_ABL & 256) ? -1.0f : (DINO_ATT_ABL & (64 | 128)) ? s[u][0][3] : max_halves(max32(s[u]));  // 128: no tile maximum only (a score stands in: extra rescales); 256: no maximum, never a rescale after tile 0  // tile maximum relative to m_run
             const bool first = jt == 0;             // m_run = 0 is not a real reference yet: take the tile maximum, whatever it is
             const bool need = first || mx > THR;
             if (__any(need)) {  // wave-uniform; lanes that do not need it shift by d = 0 (alpha = 1)
