@@ -120,6 +120,21 @@ def test_config3_vit_l_batch32_full_depth(api, pkg, ggufs):
     np.testing.assert_allclose(got["probs"].sum(-1), 1.0, atol=1e-5)
 
 
+def test_config3_forward_is_bitwise_repeatable(api, pkg, ggufs):
+    """The persistent GEMM keeps LDS-DMA in flight across barriers and stages the next tile under the current one's epilogue: a
+    stale-buffer race would show up as a RARE difference between runs of the same input.  Twelve full ViT-L forwards at batch 24
+    (whole rounds of 256-row tiles + 192-row tails + the small-tile tail plan) must agree bit for bit; tools/soak_determinism.py is
+    the long version (80 x batch 32, 30 x ViT-g, 200 x batch 1: all identical on the round-2 kernels)."""
+    imgs = pkg.synth.synthetic_images(24, 518, 518, seed=11)
+    sess = api.Session(api.Model(ggufs("large"), classify=True))
+    ref = sess.predict(imgs, classify=True, want=("logits", "patch_tokens"))
+    assert np.isfinite(ref["logits"]).all()
+    for _ in range(11):
+        out = sess.predict(imgs, classify=True, want=("logits", "patch_tokens"))
+        assert np.array_equal(out["logits"], ref["logits"])
+        assert np.array_equal(out["patch_tokens"], ref["patch_tokens"])
+
+
 @pytest.mark.parametrize("wtype", ["q8_0", "q4_0"])
 def test_config5_vit_l_quantised_full_size(api, pkg, ggufs, wtype):
     """BASELINE configs[4] at ViT-L size: q8_0 / q4_0 GGUF -> dequantised on the device at load -> f16 MFMA path, all 24
