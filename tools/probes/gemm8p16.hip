@@ -169,6 +169,54 @@ __global__ __launch_bounds__(512) void gemm8p(const _Float16* __restrict__ A, co
     BAR();
     if (!(VARIANT & 4) && wr == 1) BAR();  // wave-row 1 runs one barrier behind wave-row 0
 
+    if (VARIANT & 128) {
+        // FOUR sections per K-tile instead of eight: a phase = one token half x BOTH column halves (32 MFMAs per MMA section), the
+        // column fragments of the whole K-tile stay in registers (wf + wg: 24 reads per K-tile instead of 28).  Half the barriers.
+        // Hazards: a slot is re-staged ONE phase after its last read, so the reads are waited for BEFORE the barrier that ends the
+        // MEM section (the staggered partner's reads have returned when this wave passes the barrier and re-stages the slot).
+#define MMA4(QA)                                                                                                          \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                  \
+            acc[QA][0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[i][ks]),              \
+                                                                      __builtin_bit_cast(f16x8, wf[j][ks]), acc[QA][0][i][j], 0, 0, 0); \
+            acc[QA][1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xf[i][ks]),              \
+                                                                      __builtin_bit_cast(f16x8, wg[j][ks]), acc[QA][1][i][j], 0, 0, 0); \
+        }                                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                                    \
+            asm volatile("" : "+v"(acc[QA][0][i][0]), "+v"(acc[QA][0][i][1]), "+v"(acc[QA][1][i][0]), "+v"(acc[QA][1][i][1])); \
+    }
+#define PHASE_END4(QA) \
+    WAIT_LGKM0(); BAR(); \
+    MMA4(QA)           \
+    BAR()
+#define RDW4(DST, B_, BO)                                                           \
+    {                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                          \
+            const unsigned a__ = wa[ks] + (BO) + 32768u + (B_) * 16384u;            \
+            DSR(DST[0][ks], a__, 0);                                                \
+            DSR(DST[1][ks], a__, 2048);                                             \
+        }                                                                           \
+    }
+        for (int t = 0; t < nk; ++t) {
+            const unsigned bo = (unsigned)(t & 1) * 65536u;
+            // phase A: token half 0
+            READ_A(bo + 0u);
+            RDW4(wf, 0, bo) RDW4(wg, 1, bo)
+            if (t + 1 < nk) { stage(1, t + 1); stage(2, t + 1); }
+            PHASE_END4(0)
+            // phase B: token half 1
+            READ_A(bo + 16384u);
+            if (t + 2 < nk) {
+                stage(0, t + 2); stage(3, t + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            PHASE_END4(1)
+        }
+    } else
     if (VARIANT & 64) {
         // Balanced fragment reads: 8 / 8 / 4 / 4 per phase instead of 12 / 4 / 8 / 4, 24 per K-tile instead of 28 (W0 stays in
         // registers, nothing is read twice).  X0 blocks 0-1 of K-tile t+1 are read in phase 3 of K-tile t: the counted wait that
