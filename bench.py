@@ -36,6 +36,13 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def parity_bound(args) -> float:
+    """Stated logit tolerance of a bench configuration, relative to max(1, max|logit|)."""
+    if args.dtype != "f16" or args.wtype != "f16":
+        return 2e-2
+    return 2e-3 if args.model == "giant" else 1e-3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,8 +134,14 @@ def main():
         sess.sync()
         allp = D.gather_rows(dist, torch, plog, world)
         bcast_ok = bool((allp == allp[0:1]).all().item()) and bool(torch.isfinite(allp).all().item())
-        if rank == 0 and not bcast_ok:
-            raise SystemExit("ranks disagree on the probe image: the broadcast weight arena is not identical everywhere")
+        # every rank gathered the same rows, so every rank reaches the same verdict and exits together (no rank is left waiting in
+        # a later barrier); the max-reduction makes that explicit even if a gather ever became rank-dependent
+        bcast_ok = D.max_over_ranks(dist, torch, 0.0 if bcast_ok else 1.0, f"cuda:{local}") == 0.0
+        if not bcast_ok:
+            if rank == 0:
+                print("ranks disagree on the probe image: the broadcast weight arena is not identical everywhere", file=sys.stderr)
+            dist.destroy_process_group()
+            raise SystemExit(3)
 
     B, S = args.batch, args.size
     T = model.tokens(S, S)
@@ -166,58 +179,62 @@ def main():
     # ---- BASELINE configs[3] (N > 1 only): ViT-g/14 SwiGLU bf16, global batch 64 = N x 64/N, weights by RCCL broadcast ----
     config4 = None
     if dist is not None and not args.no_config4 and 64 % world == 0:
-        del sess
-        model.close()
-        torch.cuda.empty_cache()
-        gpath = os.path.join(tempfile.gettempdir(), f"dinov2_giant_r{args.registers}_f16_seed42.gguf")
-        if rank == 0 and not os.path.exists(gpath):
-            tmp = gpath + f".{os.getpid()}.tmp"
-            pkg.synth.write_synthetic_gguf(tmp, "giant", registers=args.registers, num_classes=num_classes, seed=42)
-            os.replace(tmp, gpath)
-        dist.barrier()
-        gm = api.Model(gpath, device=local, dtype=api.BF16, classify=True, skip_tensor_data=(rank != 0))
-        gptr, gbytes = gm.arena()
-        garena = torch.as_tensor(D.DevPtr(gptr, gbytes), device=f"cuda:{local}")
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        D.broadcast_weights(dist, garena, src=0)
-        torch.cuda.synchronize()
-        g_bcast_ms = D.max_over_ranks(dist, torch, (time.perf_counter() - t0) * 1e3, f"cuda:{local}")
-        gs = api.Session(gm)
-        lo, hi = D.shard_range(64, world, rank)
-        gB = hi - lo
-        gimgs = torch.randn((gB, 3, S, S), generator=gen, device=f"cuda:{local}", dtype=torch.float32)
-        glog = torch.empty((gB, num_classes), device=f"cuda:{local}", dtype=torch.float32)
-        torch.cuda.synchronize()
+        try:
+            del sess
+            model.close()
+            torch.cuda.empty_cache()
+            sess = model = None
+            gpath = os.path.join(tempfile.gettempdir(), f"dinov2_giant_r{args.registers}_f16_seed42.gguf")
+            if rank == 0 and not os.path.exists(gpath):
+                tmp = gpath + f".{os.getpid()}.tmp"
+                pkg.synth.write_synthetic_gguf(tmp, "giant", registers=args.registers, num_classes=num_classes, seed=42)
+                os.replace(tmp, gpath)
+            dist.barrier()
+            gm = api.Model(gpath, device=local, dtype=api.BF16, classify=True, skip_tensor_data=(rank != 0))
+            gptr, gbytes = gm.arena()
+            garena = torch.as_tensor(D.DevPtr(gptr, gbytes), device=f"cuda:{local}")
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            D.broadcast_weights(dist, garena, src=0)
+            torch.cuda.synchronize()
+            g_bcast_ms = D.max_over_ranks(dist, torch, (time.perf_counter() - t0) * 1e3, f"cuda:{local}")
+            gs = api.Session(gm)
+            lo, hi = D.shard_range(64, world, rank)
+            gB = hi - lo
+            gimgs = torch.randn((gB, 3, S, S), generator=gen, device=f"cuda:{local}", dtype=torch.float32)
+            glog = torch.empty((gB, num_classes), device=f"cuda:{local}", dtype=torch.float32)
+            torch.cuda.synchronize()
 
-        def gstep():
-            gs.predict_device(gimgs.data_ptr(), gB, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=glog.data_ptr())
+            def gstep():
+                gs.predict_device(gimgs.data_ptr(), gB, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=glog.data_ptr())
 
-        for _ in range(2):
-            gstep()
-        dist.barrier()
-        gs.sync()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        gsteps = max(2, min(args.steps, 5))
-        for _ in range(gsteps):
-            gstep()
-        gs.sync()
-        torch.cuda.synchronize()
-        g_el = D.max_over_ranks(dist, torch, time.perf_counter() - t0, f"cuda:{local}")
-        g_fin = D.max_over_ranks(dist, torch, 0.0 if bool(torch.isfinite(glog).all()) else 1.0, f"cuda:{local}")
-        gcfg = pkg.synth.CONFIGS["giant"]
-        ggf = pkg.synth.flops_per_image(gcfg, S, S, args.registers, num_classes) / 1e9
-        config4 = {"workload": f"dinov2-giant (ViT-g/14, SwiGLU, {args.registers} registers) bf16, {S}x{S}, global batch 64 = {world} x {gB}",
-                   "value": round(64 * gsteps / g_el, 2), "unit": "images/sec", "ms_per_step": round(g_el / gsteps * 1e3, 3), "steps": gsteps,
-                   "dtype": "bf16", "gflop_per_image": round(ggf, 1), "tflops_per_gpu": round(64 * gsteps / g_el * ggf / 1e3 / world, 1),
-                   "weight_broadcast_ms": round(g_bcast_ms, 2), "arena_mb": round(gbytes / 1e6, 1), "finite": g_fin == 0.0}
-        del gs
-        gm.close()
-        # the ViT-L model again for the rank-0 measurements below
-        model = api.Model(path, device=local, dtype=dt, classify=True) if rank == 0 else None
-        sess = api.Session(model) if rank == 0 else None
+            for _ in range(2):
+                gstep()
+            dist.barrier()
+            gs.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            gsteps = max(2, min(args.steps, 5))
+            for _ in range(gsteps):
+                gstep()
+            gs.sync()
+            torch.cuda.synchronize()
+            g_el = D.max_over_ranks(dist, torch, time.perf_counter() - t0, f"cuda:{local}")
+            g_fin = D.max_over_ranks(dist, torch, 0.0 if bool(torch.isfinite(glog).all()) else 1.0, f"cuda:{local}")
+            gcfg = pkg.synth.CONFIGS["giant"]
+            ggf = pkg.synth.flops_per_image(gcfg, S, S, args.registers, num_classes) / 1e9
+            config4 = {"workload": f"dinov2-giant (ViT-g/14, SwiGLU, {args.registers} registers) bf16, {S}x{S}, global batch 64 = {world} x {gB}",
+                       "value": round(64 * gsteps / g_el, 2), "unit": "images/sec", "ms_per_step": round(g_el / gsteps * 1e3, 3), "steps": gsteps,
+                       "dtype": "bf16", "gflop_per_image": round(ggf, 1), "tflops_per_gpu": round(64 * gsteps / g_el * ggf / 1e3 / world, 1),
+                       "weight_broadcast_ms": round(g_bcast_ms, 2), "arena_mb": round(gbytes / 1e6, 1), "finite": g_fin == 0.0}
+            del gs
+            gm.close()
+        finally:
+            # the ViT-L model again for the rank-0 measurements below, whatever happened in the leg
+            if rank == 0 and model is None:
+                model = api.Model(path, device=local, dtype=dt, classify=True)
+                sess = api.Session(model)
 
     if rank != 0:
         if dist is not None:
@@ -285,20 +302,30 @@ def main():
                 "sustained_mfma_tflops_random_operands": 1750.0, "frac_of_sustained": round(ach / 1750.0, 4)}
 
     # ---- p50 latency at batch 1 (the other half of BASELINE.json's metric) ----
-    p50 = p99 = None
+    p50 = p99 = p50_ll = p99_ll = None
     if not args.no_latency:
         one = imgs[:1].contiguous()
-        torch.cuda.synchronize()
-        lat = []
-        for i in range(220):  # 20 warm-up + 200 timed forwards
+
+        def latency(sx):
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            sess.predict_device(one.data_ptr(), 1, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=logits.data_ptr(),
-                                probs_ptr=probs.data_ptr())
-            sess.sync()
-            lat.append((time.perf_counter() - t0) * 1e3)
-        p50 = round(float(np.median(lat[20:])), 3)
-        p99 = round(float(np.percentile(lat[20:], 99)), 3)
+            lat = []
+            for i in range(220):  # 20 warm-up + 200 timed forwards
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                sx.predict_device(one.data_ptr(), 1, S, S, classify=True, layout=api.RGB_CHW, logits_ptr=logits.data_ptr(),
+                                  probs_ptr=probs.data_ptr())
+                sx.sync()
+                lat.append((time.perf_counter() - t0) * 1e3)
+            return round(float(np.median(lat[20:])), 3), round(float(np.percentile(lat[20:], 99)), 3)
+
+        # the library's default: batch-invariant kernels (this image alone == this image inside the batch of B, bit for bit)
+        p50, p99 = latency(sess)
+        # opt-in low-latency mode (dinov2_hip_load_opts.batch_invariant = 0: intra-workgroup split-K for the two N = hidden GEMMs)
+        m_ll = api.Model(path, device=local, dtype=dt, classify=True, batch_invariant=False)
+        s_ll = api.Session(m_ll)
+        p50_ll, p99_ll = latency(s_ll)
+        del s_ll
+        m_ll.close()
 
     # ---- side measurement, NOT the headline: the same batch split over two sessions (two HIP streams) on this GPU.  The other
     #      stream's kernels fill the idle CUs of a GEMM's last round; per-kernel durations of overlapped launches would mean
@@ -356,7 +383,12 @@ def main():
                          f"times it), best of OpenMP teams of 8 / 16 / 32 threads (host reports {os.cpu_count()} CPUs)",
                "value_4_threads": round(1.0 / t4_s, 4), "note_4_threads": "the reference's default -t 4 (dinov2.h:62)",
                "max_abs_logit_diff_vs_gpu": round(dl, 6), "max_abs_logit": round(big, 4),
-               "rel_logit_diff_vs_gpu": round(dl / max(1.0, big), 6), "parity_bound": "max|d_logit| <= 1e-3 * max(1, max|logit|)"}
+               "rel_logit_diff_vs_gpu": round(dl / max(1.0, big), 6),
+               # the bound that applies to THIS run: relative to the largest logit; f16 weights + f16 compute 1e-3
+               # (ViT-g 40 layers 2e-3); bf16 compute 2e-2; quantised GGUFs are checked against the ggml-mode oracle here
+               # (activations quantised to q8_0 blocks as well), where the stated bound is 2e-2
+               "parity_bound": f"max|d_logit| <= {parity_bound(args):g} * max(1, max|logit|)",
+               "within_bound": bool(dl <= parity_bound(args) * max(1.0, big))}
         del got
 
     out = {
@@ -371,6 +403,8 @@ def main():
                    "global_batch": world * B, "tokens_per_image": T, "parallelism": f"dp{world}",
                    "gflop_per_image": round(gflop_img, 1)},
         "p50_latency_ms_batch1": p50, "p99_latency_ms_batch1": p99,
+        "latency_mode": "default (batch_invariant = 1: batch-1 bits == the image's bits inside any batch)",
+        "p50_latency_ms_batch1_low_latency": p50_ll, "p99_latency_ms_batch1_low_latency": p99_ll,
         "two_sessions_images_per_sec": two_stream,
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),

@@ -185,7 +185,7 @@ class Model:
 
     def __init__(self, path: str, *, device: int = 0, dtype: int = F16, classify: bool = True,
                  skip_tensor_data: bool = False, pool_const_divisor: bool = True, pool_includes_registers: bool = True,
-                 batch_invariant: bool = False):
+                 batch_invariant: bool = True):
         L = lib()
         o = LoadOpts()
         L.dinov2_hip_default_load_opts(C.byref(o))
@@ -272,7 +272,7 @@ class Group:
     batch split contiguously, outputs landing at the shard offsets of the caller's arrays."""
 
     def __init__(self, path: str, devices=None, *, dtype: int = F16, classify: bool = True, broadcast: bool = True,
-                 batch_invariant: bool = False):
+                 batch_invariant: bool = True):
         L = lib()
         o = GroupOpts()
         L.dinov2_hip_default_group_opts(C.byref(o))
@@ -296,6 +296,10 @@ class Group:
     def predict(self, images: np.ndarray, *, classify: bool = False, layout: int = RGB_CHW, topk: int = 0,
                 want=("cls", "patch_tokens", "logits", "probs")) -> dict:
         img = np.ascontiguousarray(images, dtype=np.uint8 if layout == U8_BGR_HWC else np.float32)
+        if img.ndim == 3:  # one image -> a batch of one, like Session.predict
+            img = img[None]
+        if img.ndim != 4 or (img.shape[1] if layout == RGB_CHW else img.shape[3]) != 3:
+            raise ValueError(f"expected [B, 3, H, W] (RGB_CHW) or [B, H, W, 3] images, got shape {img.shape}")
         B = img.shape[0]
         hh, ww = (img.shape[2], img.shape[3]) if layout == RGB_CHW else (img.shape[1], img.shape[2])
         out, o = _alloc_outputs(self.hparams, B, hh, ww, layout, classify, topk, want)

@@ -356,6 +356,8 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
+    // rows are fetched with 16-byte global -> LDS DMA pieces and 16-byte vector loads: strides must keep rows 16-byte aligned
+    if (a.lda < 0 || a.ldw < 0 || lda_ % 8 != 0 || ldw_ % 8 != 0 || lda_ < (size_t)a.K || ldw_ < (size_t)a.K) return hipErrorInvalidValue;
     if ((size_t)a.M * lda_ * 2 >= ((size_t)1 << 32) || (size_t)a.N * ldw_ * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
     static const int forced = [] {
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");

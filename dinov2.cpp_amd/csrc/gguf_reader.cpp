@@ -159,7 +159,7 @@ bool GgufFile::open(const std::string& path, std::string* err) {
     }
     uint64_t align = 32;
     if (const GgufValue* a = find("general.alignment")) align = a->u ? a->u : 32;
-    if (align > ((uint64_t)1 << 30)) {
+    if (!gguf_alignment_ok(align)) {
         *err = "implausible general.alignment";
         return false;
     }

@@ -68,4 +68,7 @@ private:
     std::map<std::string, size_t> index_;
 };
 
+// general.alignment as the loader AND the quantiser accept it (one rule): a power of two in [1, 2^20]; 0 / absent = 32
+inline bool gguf_alignment_ok(uint64_t a) { return a >= 1 && a <= ((uint64_t)1 << 20) && (a & (a - 1)) == 0; }
+
 }  // namespace dinov2

@@ -17,6 +17,7 @@
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -48,15 +49,19 @@ struct Rccl {
     const char* (*GetErrorString)(int) = nullptr;
     bool load(std::string* why) {
         if (so) return true;
+        void* h = nullptr;
+        std::string last;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            so = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (so) break;
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) break;
+            const char* e = dlerror();  // ONE call: dlerror() clears the state it reports
+            if (e) last = e;
         }
-        if (!so) {
-            *why = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "?");
+        if (!h) {
+            *why = "cannot load librccl: " + (last.empty() ? std::string("?") : last);
             return false;
         }
-        auto sym = [&](const char* n) { return dlsym(so, n); };
+        auto sym = [&](const char* n) { return dlsym(h, n); };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
@@ -65,8 +70,12 @@ struct Rccl {
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
         if (!CommInitAll || !CommDestroy || !Broadcast || !GroupStart || !GroupEnd || !GetErrorString) {
             *why = "librccl lacks an expected symbol";
+            CommInitAll = nullptr; CommDestroy = nullptr; Broadcast = nullptr;
+            GroupStart = nullptr; GroupEnd = nullptr; GetErrorString = nullptr;
+            dlclose(h);  // `so` stays null: the next call tries again instead of calling through null pointers
             return false;
         }
+        so = h;
         return true;
     }
 };
@@ -227,7 +236,19 @@ extern "C" int dinov2_hip_group_create(const char* gguf_path, const dinov2_hip_g
     }
     // RCCL wants one communicator rank per distinct device; a list that names a device twice (two sessions on one GPU: a
     // legitimate serving setup, and how the 1-GPU test box exercises the split) makes every rank read the file itself
-    const bool bcast = o.broadcast != 0 && distinct;
+    bool bcast = o.broadcast != 0 && distinct;
+    if (bcast) {  // decided BEFORE ranks > 0 skip their tensor data: without librccl every rank reads the file itself
+        std::string why;
+        std::lock_guard<std::mutex> lk(g_rccl_mu);
+        if (!g_rccl.load(&why)) {
+            if (getenv("DINOV2_HIP_GROUP_REQUIRE_RCCL")) {
+                set_err(err, errlen, "%s", why.c_str());
+                return DINOV2_HIP_ERR_HIP;
+            }
+            fprintf(stderr, "dinov2_hip_group_create: %s -- every device reads the GGUF itself\n", why.c_str());
+            bcast = false;
+        }
+    }
 
     std::unique_ptr<dinov2_hip_group, void (*)(dinov2_hip_group*)> g(new dinov2_hip_group(), dinov2_hip_group_free);
     for (size_t i = 0; i < devs.size(); ++i) {

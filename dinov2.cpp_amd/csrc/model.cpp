@@ -150,6 +150,7 @@ extern "C" void dinov2_hip_default_load_opts(dinov2_hip_load_opts* o) {
     o->skip_tensor_data = 0;
     o->quirk_pool_const_divisor = 1;
     o->quirk_pool_includes_registers = 1;
+    o->batch_invariant = 1;
 }
 
 extern "C" int dinov2_hip_abi_version(void) { return DINOV2_HIP_ABI_VERSION; }

@@ -24,7 +24,7 @@ struct dinov2_hip_model {
     dinov2::DType dt = dinov2::DT_F16;
     int device = 0;
     bool quirk_const_div = true, quirk_pool_regs = true;
-    bool batch_invariant = false;  // dinov2_hip_load_opts.batch_invariant: never split K
+    bool batch_invariant = true;  // dinov2_hip_load_opts.batch_invariant: never split K
     int kpe = 0, kpe_pad = 0;  // patch-embed K (3*p*p) and its padding to a multiple of 64
     char* arena = nullptr;     // ONE allocation, like model.buffer (dinov2.cpp:341)
     size_t arena_bytes = 0;

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../../include/dinov2_hip.h"
+#include "gguf_reader.h"
 
 namespace {
 
@@ -185,7 +186,8 @@ extern "C" int dinov2_hip_quantize(const char* fname_inp, const char* fname_out,
         t.off = r.get<uint64_t>();
         tis.push_back(std::move(t));
     }
-    if (!r.ok || align == 0 || align > (1u << 20)) { fail(err, errlen, "truncated or corrupt GGUF metadata"); return DINOV2_HIP_ERR_FORMAT; }
+    if (align == 0) align = 32;  // same reading as the loader (gguf_reader.cpp)
+    if (!r.ok || !dinov2::gguf_alignment_ok(align)) { fail(err, errlen, "truncated or corrupt GGUF metadata"); return DINOV2_HIP_ERR_FORMAT; }
     const size_t data0 = (r.p + align - 1) / align * align;
     if (data0 > buf.size() && !tis.empty()) { fail(err, errlen, "GGUF data section starts past the end of the file"); return DINOV2_HIP_ERR_FORMAT; }
 

@@ -58,10 +58,13 @@ typedef struct dinov2_hip_load_opts {
                                  receive the arena by RCCL broadcast (dinov2_hip_model_arena)                        */
     int32_t quirk_pool_const_divisor;      /* 1 (default): pooled = sum / (img_size/patch)^2  (dinov2.cpp:794,800-803) */
     int32_t quirk_pool_includes_registers; /* 1 (default): register tokens are pooled too      (dinov2.cpp:772-776)     */
-    int32_t batch_invariant; /* 0 (default): at small batches the two N = hidden GEMMs split their K loop inside the workgroup
-                                (result = acc_lo + acc_hi): reproducible run to run, but an image's last bits can then depend
-                                on the size of the batch it came in.  1: every kernel sums K in one order -- B images == B
-                                independent forwards bit for bit at any batch size (costs ~0.5 ms of batch-1 latency on ViT-L) */
+    int32_t batch_invariant; /* 1 (default, set by dinov2_hip_default_load_opts): every kernel sums K in one order -- B images == B
+                                independent forwards BIT FOR BIT, whatever the batch size, the chunking of an over-long batch or
+                                the number of devices a dinov2_hip_group shards it over.
+                                0 (opt-in low-latency mode): at small batches the two N = hidden GEMMs split their K loop inside
+                                the workgroup (result = acc_lo + acc_hi): reproducible run to run, but an image's last bits then
+                                depend on the size of the batch (shard, remainder chunk) it was computed in -- equal to the
+                                batched result to the stated bound only.  Buys ~0.2 ms of batch-1 latency on ViT-L/14 @518.  */
     int32_t reserved[9];
 } dinov2_hip_load_opts;
 

@@ -400,10 +400,11 @@ def test_gemm_random_shapes_all_plans(api, seed):
 @pytest.mark.parametrize("M,N,K,epi", [(1374, 1024, 4096, EPI_RESID), (1374, 1024, 1024, EPI_RESID), (1374, 768, 3072, EPI_RESID),
                                        (700, 1536, 4096, EPI_RESID), (1000, 1024, 2048, 5)])
 def test_gemm_intra_workgroup_split_k(api, dt, M, N, K, epi):
-    """GemmArgs.allow_ksplit (the default plan of a batch-1 forward for attn-out / FFN-out: fewer 64 x 128 tiles than CUs, K >= 1 024):
+    """GemmArgs.allow_ksplit (the plan of a batch-1 forward for attn-out / FFN-out when the model was loaded with batch_invariant = 0:
+    fewer 64 x 128 tiles than CUs, K >= 1 024):
     two wave groups multiply the two halves of K for the same tile and group 1 hands its accumulators over through LDS.  Against
     float64 numpy on the rounded operands; against the un-split kernel (same result to one f32 rounding of the final add, NOT bit for
-    bit -- which is why the plan is opt-out through dinov2_hip_load_opts.batch_invariant); bit-reproducible run to run."""
+    bit -- which is why the plan is opt-IN through dinov2_hip_load_opts.batch_invariant = 0); bit-reproducible run to run."""
     rng = np.random.default_rng(M + N + K + dt)
     A, W = _round(rng.standard_normal((M, K)), dt), _round(rng.standard_normal((N, K)) * 0.05, dt)
     bias, ls = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)

@@ -229,20 +229,28 @@ def test_odd_batch_and_session_reuse_across_shapes(api, golden_dir):
 
 
 def test_image_result_independent_of_batch_size(api, pkg, tmp_path):
-    """ViT-L/14 shapes (4 layers).  With dinov2_hip_load_opts.batch_invariant = 1 an image alone (batch 1: 64x128-tile GEMMs,
-    pipelined attention kernel) and the same image inside a batch of 24 (persistent 256x256 GEMM, high-occupancy attention
-    kernel) give identical bits.  In the default mode a batch-1 forward splits the K loops of attn-out / FFN-out inside the
-    workgroup (acc_lo + acc_hi): reproducible run to run, equal to the batched result to f32 summation-order accuracy."""
+    """ViT-L/14 shapes (4 layers).  By default (dinov2_hip_load_opts.batch_invariant = 1) an image alone (batch 1: small-tile
+    GEMMs, pipelined attention kernel) and the same image inside a batch of 24 (persistent 256x256 GEMM, high-occupancy attention
+    kernel) give identical bits -- also when the batch is cut into chunks with a remainder of one image.  In the opt-in
+    low-latency mode (batch_invariant = 0) a batch-1 forward splits the K loops of attn-out / FFN-out inside the workgroup
+    (acc_lo + acc_hi): reproducible run to run, equal to the batched result to f32 summation-order accuracy."""
     path = str(tmp_path / "large4b.gguf")
     pkg.synth.write_synthetic_gguf(path, "large", registers=4, num_classes=1000, seed=7, layers=4)
     imgs = pkg.synth.synthetic_images(24, 518, 518, seed=7)
-    sess = api.Session(api.Model(path, classify=True, batch_invariant=True))
+    sess = api.Session(api.Model(path, classify=True))  # the default IS batch-invariant
     full = sess.predict(imgs, classify=True)
     for b in (0, 23):
         one = sess.predict(imgs[b:b + 1], classify=True)
         assert np.array_equal(one["logits"][0], full["logits"][b])
         assert np.array_equal(one["patch_tokens"][0], full["patch_tokens"][b])
-    fast = api.Session(api.Model(path, classify=True))
+    # a chunked predict whose last chunk holds ONE image (ADVICE r2: the remainder chunk must not get other bits)
+    os.environ["DINOV2_HIP_MAX_CHUNK"] = "23"
+    try:
+        chunked = api.Session(api.Model(path, classify=True)).predict(imgs, classify=True)
+    finally:
+        del os.environ["DINOV2_HIP_MAX_CHUNK"]
+    assert np.array_equal(chunked["logits"], full["logits"]) and np.array_equal(chunked["patch_tokens"], full["patch_tokens"])
+    fast = api.Session(api.Model(path, classify=True, batch_invariant=False))
     assert np.array_equal(fast.predict(imgs, classify=True)["logits"], full["logits"])  # large batches never split
     one = fast.predict(imgs[23:24], classify=True)
     again = fast.predict(imgs[23:24], classify=True)
