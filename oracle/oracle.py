@@ -55,6 +55,9 @@ def _lib():
         _LIB.oracle_forward.restype = C.c_int
         _LIB.oracle_forward.argtypes = [C.POINTER(_Model), _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp, _fp,
                                         C.c_int]
+        _dp = C.POINTER(C.c_double)
+        _LIB.oracle_forward_exact.restype = C.c_int
+        _LIB.oracle_forward_exact.argtypes = [C.POINTER(_Model), _fp, C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, _dp, C.c_int]
         _LIB.oracle_interpolate_pos_embed.restype = None
         _LIB.oracle_interpolate_pos_embed.argtypes = [_fp, C.c_int, C.c_int, C.c_int, C.c_int, _fp]
     return _LIB
@@ -182,6 +185,33 @@ class OracleModel:
                                    _p(out.get("hidden")), nthreads)
         if rc != 0:
             raise RuntimeError(f"oracle_forward failed: {rc}")
+        return out
+
+    def forward_exact(self, img_chw: np.ndarray, classify: bool = False, nthreads: int = 0) -> dict:
+        """The same graph on the same stored weights in DOUBLE with no intermediate rounding (oracle_forward_exact): the value
+        that ggml's f32/f16 arithmetic and the HIP path's f16-MFMA arithmetic both approximate.  float64 outputs."""
+        if nthreads <= 0:
+            nthreads = int(os.environ.get("OMP_NUM_THREADS", 0)) or min(16, os.cpu_count() or 1)
+        img = np.ascontiguousarray(img_chw, dtype=np.float32)
+        assert img.ndim == 3 and img.shape[0] == 3
+        _, hh, ww = img.shape
+        H, R = self.hidden, self.registers
+        P = (hh // self.patch) * (ww // self.patch)
+        if classify and not self.has_head:
+            raise ValueError("model has no classifier head")
+        out = {"cls": np.empty(H, np.float64), "patch_tokens": np.empty((P + (R if classify else 0), H), np.float64)}
+        if classify:
+            out["logits"] = np.empty(self.num_classes, np.float64)
+            out["probs"] = np.empty(self.num_classes, np.float64)
+        dp = C.POINTER(C.c_double)
+
+        def d(a):
+            return a.ctypes.data_as(dp) if a is not None else dp()
+
+        rc = _lib().oracle_forward_exact(C.byref(self.c), _p(img), hh, ww, int(classify), d(out["cls"]), d(out["patch_tokens"]),
+                                         d(out.get("logits")), d(out.get("probs")), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_forward_exact failed: {rc}")
         return out
 
     def interpolate_pos_embed(self, h_new: int, w_new: int) -> np.ndarray:

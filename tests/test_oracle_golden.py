@@ -34,6 +34,31 @@ def test_oracle_matches_hf_in_f32_mode(golden_dir, manifest, name):
 
 
 @pytest.mark.parametrize("name", FIXTURES)
+def test_oracle_exact_mode(golden_dir, manifest, name):
+    """oracle_forward_exact (double everywhere, no intermediate rounding, the same stored weights) against the HF fixtures: HF's
+    own f32 arithmetic is the only difference (<= 2e-5 on the tokens), and the f32-mode oracle is at least as close to the exact
+    result as it is to HF.  The ggml-mode oracle (f16 activation rounding + f16 GELU table) sits O(1e-4) from exact."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    path = os.path.join(golden_dir, name + ".gguf")
+    f32 = OracleModel(path, act_round=0, gelu_f16_lut=False)
+    f32.set(conv_round=0)
+    ggml = OracleModel(path)
+    for key in manifest[name]["sizes"]:
+        ex = f32.forward_exact(g[f"img_{key}"], classify=True)
+        assert ex["logits"].dtype == np.float64
+        assert np.abs(ex["cls"] - g[f"final_{key}"][0]).max() < 2e-5
+        assert np.abs(ex["patch_tokens"] - g[f"final_{key}"][1:]).max() < 2e-5
+        assert np.abs(ex["logits"] - g[f"logits_{key}"]).max() < 5e-6
+        assert np.abs(ex["probs"] - g[f"probs_{key}"]).max() < 1e-6
+        o32 = f32.forward(g[f"img_{key}"], classify=True)
+        assert np.abs(o32["logits"] - ex["logits"]).max() < 5e-6
+        og = ggml.forward(g[f"img_{key}"], classify=True)
+        assert 0 < np.abs(og["logits"] - ex["logits"]).max() < 2e-3
+        # the switches of the model do not reach the exact path
+        assert np.array_equal(ggml.forward_exact(g[f"img_{key}"], classify=True)["logits"], ex["logits"])
+
+
+@pytest.mark.parametrize("name", FIXTURES)
 def test_oracle_pos_embed_interpolation(golden_dir, manifest, name):
     """cv::resize(INTER_CUBIC) restatement == torch bicubic (align_corners=False, no antialias) to f32 round-off."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
