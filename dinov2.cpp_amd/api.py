@@ -63,7 +63,7 @@ class Output(C.Structure):
 
 class GroupOpts(C.Structure):
     _fields_ = [("load", LoadOpts), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)), ("broadcast", C.c_int32),
-                ("reserved", C.c_int32 * 8)]
+                ("streams_per_device", C.c_int32), ("reserved", C.c_int32 * 7)]
 
 
 _lib = None
@@ -118,6 +118,13 @@ def lib():
     L.dinov2_hip_group_broadcast_ms.argtypes = [vp]
     L.dinov2_hip_group_broadcast_ms.restype = C.c_double
     L.dinov2_hip_group_predict.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, cp, sz]
+    L.dinov2_hip_group_submit.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, C.POINTER(C.c_int64), cp, sz]
+    L.dinov2_hip_group_wait.argtypes = [vp, C.c_int64, cp, sz]
+    L.dinov2_hip_fetch.argtypes = [vp, C.POINTER(Output), cp, sz]
+    L.dinov2_hip_host_alloc.argtypes = [sz]
+    L.dinov2_hip_host_alloc.restype = vp
+    L.dinov2_hip_host_free.argtypes = [vp]
+    L.dinov2_hip_host_free.restype = None
     L.dinov2_hip_interpolate_pos_embed.argtypes = [vp, i32, i32, vp]
     L.dinov2_hip_preprocess_size.argtypes = [i32, i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.dinov2_hip_preprocess.argtypes = [i32, vp, i32, i32, i32, vp]
@@ -267,18 +274,34 @@ def _alloc_outputs(hp, B, hh, ww, layout, classify, topk, want):
     return out, o
 
 
+def pinned_empty(shape, dtype=np.float32) -> np.ndarray:
+    """numpy array over page-locked host memory (dinov2_hip_host_alloc): host <-> device copies of such buffers run at the full
+    PCIe rate.  The memory is released when the array (and every view of it) is garbage-collected."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = lib().dinov2_hip_host_alloc(max(n, 1))
+    if not ptr:
+        raise MemoryError(f"dinov2_hip_host_alloc({n}) failed")
+    buf = (C.c_char * max(n, 1)).from_address(ptr)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    import weakref
+    weakref.finalize(buf, lib().dinov2_hip_host_free, ptr)
+    return arr
+
+
 class Group:
-    """dinov2_hip_group: N devices behind one handle -- one host thread + session per device inside the library, the global
-    batch split contiguously, outputs landing at the shard offsets of the caller's arrays."""
+    """dinov2_hip_group: N devices behind one handle -- host threads + sessions per device inside the library (two lanes per
+    device by default: one lane's PCIe copies run under the other's kernels), the global batch split contiguously, outputs
+    landing at the shard offsets of the caller's arrays."""
 
     def __init__(self, path: str, devices=None, *, dtype: int = F16, classify: bool = True, broadcast: bool = True,
-                 batch_invariant: bool = True):
+                 batch_invariant: bool = True, streams_per_device: int = 2):
         L = lib()
         o = GroupOpts()
         L.dinov2_hip_default_group_opts(C.byref(o))
         o.load.compute_dtype, o.load.classify = dtype, int(classify)
         o.load.batch_invariant = int(batch_invariant)
         o.broadcast = int(broadcast)
+        o.streams_per_device = int(streams_per_device)
         if devices is not None:
             self._devs = (C.c_int32 * len(devices))(*devices)
             o.n_devices, o.devices = len(devices), self._devs
@@ -309,6 +332,34 @@ class Group:
         if rc != 0:
             raise DinoError(rc, err.value.decode(errors="replace"))
         return out
+
+    def submit(self, images: np.ndarray, *, classify: bool = False, layout: int = RGB_CHW, topk: int = 0,
+               want=("cls", "patch_tokens", "logits", "probs")):
+        """First half of predict (dinov2_hip_group_submit): returns a pending-job handle at once; up to `streams_per_device` jobs
+        may be in flight.  `images` must not be modified until wait() has returned for the handle."""
+        img = np.ascontiguousarray(images, dtype=np.uint8 if layout == U8_BGR_HWC else np.float32)
+        if img.ndim == 3:
+            img = img[None]
+        if img.ndim != 4 or (img.shape[1] if layout == RGB_CHW else img.shape[3]) != 3:
+            raise ValueError(f"expected [B, 3, H, W] (RGB_CHW) or [B, H, W, 3] images, got shape {img.shape}")
+        B = img.shape[0]
+        hh, ww = (img.shape[2], img.shape[3]) if layout == RGB_CHW else (img.shape[1], img.shape[2])
+        out, o = _alloc_outputs(self.hparams, B, hh, ww, layout, classify, topk, want)
+        i = Input(img.ctypes.data, B, hh, ww, layout, 0)
+        t = C.c_int64(-1)
+        err = _errbuf()
+        rc = lib().dinov2_hip_group_submit(self._h, C.byref(i), C.byref(o), CLASSIFY if classify else 0, C.byref(t), err, len(err))
+        if rc != 0:
+            raise DinoError(rc, err.value.decode(errors="replace"))
+        return (t.value, img, out)  # the handle keeps the input and output arrays alive
+
+    def wait(self, handle) -> dict:
+        """Second half: blocks until the job's results are in the arrays; handles are waited for in submission order."""
+        err = _errbuf()
+        rc = lib().dinov2_hip_group_wait(self._h, handle[0], err, len(err))
+        if rc != 0:
+            raise DinoError(rc, err.value.decode(errors="replace"))
+        return handle[2]
 
     def close(self):
         if getattr(self, "_h", None):

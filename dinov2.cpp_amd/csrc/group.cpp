@@ -1,10 +1,16 @@
 // group.cpp -- native multi-device driver behind the C-ABI (include/dinov2_hip.h, dinov2_hip_group_*).
 //
-// the path shards by independent images.  One HOST THREAD + one session (stream + workspace) per device, the
-// caller's global batch [B, ...] split contiguously (device g owns images [g*B/G, (g+1)*B/G), remainder to the low ranks) and
-// every device writing its outputs straight into the caller's buffers at its shard offset.  No data-path collective.  The ONE
-// collective is the load-time broadcast of rank 0's converted weight arena over xGMI: single-process RCCL
-// (ncclCommInitAll + ncclBroadcast inside a group call), so the GGUF is parsed / dequantised once instead of G times.
+// the path shards by independent images.  The caller's global batch [B, ...] is split contiguously (device g owns
+// images [g*B/G, (g+1)*B/G), remainder to the low ranks) and every device writes its outputs straight into the caller's buffers at
+// its shard offset.  No data-path collective.
+//
+// HOST BUFFERS WITHOUT A PCIe BUBBLE: each device runs `streams_per_device` (default 2) LANES -- a host thread + session
+// (stream, workspace) + input staging buffer each.  Jobs (dinov2_hip_group_submit) go to the lanes round-robin, and every
+// device works through three turnstiles in job order: host -> device copy of the shard, the forward (whole shard, one batch:
+// splitting it would cost GEMM efficiency, measured), device -> host copy of the results.  With two jobs in flight lane B copies
+// job k + 1 in while lane A computes job k, and lane A copies job k out while lane B computes job k + 1: the GPU only ever waits
+// for the first copy-in and the last copy-out.  dinov2_hip_group_predict = submit + wait (one job in flight, nothing to overlap).
+// Measured on one MI355X (tools/host_path.py, profiles/r03_host_path.json).
 //
 // This is what lets a C++ host of the reference's shape (/root/reference/inference.cpp:65, realtime.cpp:70 call dino_predict
 // from one thread) use more than one GPU; bench.py's one-process-per-GPU torch.distributed run is the other way in.
@@ -28,6 +34,15 @@
 #include "model.h"
 
 namespace {
+
+#define HIPG_TRY(expr)                                                                     \
+    do {                                                                                   \
+        const hipError_t e__ = (expr);                                                     \
+        if (e__ != hipSuccess) {                                                           \
+            set_err(err, errlen, "%s failed: %s", #expr, hipGetErrorString(e__));          \
+            return DINOV2_HIP_ERR_HIP;                                                     \
+        }                                                                                  \
+    } while (0)
 
 void set_err(char* err, size_t n, const char* fmt, ...) {
     if (!err || n == 0) return;
@@ -83,32 +98,45 @@ Rccl g_rccl;
 std::mutex g_rccl_mu;
 
 struct Job {
-    const dinov2_hip_input* in = nullptr;
-    const dinov2_hip_output* out = nullptr;
+    dinov2_hip_input in{};
+    dinov2_hip_output out{};
+    bool has_out = false;
     uint32_t flags = 0;
+    int remaining = 0;  // ranks that have not finished it yet
+    int rc = 0;
+    char err[256] = {0};
 };
 
 }  // namespace
 
 struct dinov2_hip_group {
+    struct Lane {  // one host thread + session + input staging buffer
+        dinov2_hip_session* session = nullptr;
+        hipStream_t stream = nullptr;
+        void* stage = nullptr;  // device copy of this lane's input images
+        size_t stage_bytes = 0;
+        std::thread th;
+    };
     struct Rank {
         int device = 0;
         dinov2_hip_model* model = nullptr;
-        dinov2_hip_session* session = nullptr;
-        std::thread th;
-        int rc = 0;
-        char err[256] = {0};
+        std::vector<std::unique_ptr<Lane>> lanes;
+        // the three turnstiles of a device, each passed in job order: copy-in, forward, copy-out
+        std::mutex turn_mu;
+        std::condition_variable turn_cv;
+        int64_t turn[3] = {0, 0, 0};
     };
     std::vector<std::unique_ptr<Rank>> ranks;
+    int nlanes = 1;
     double broadcast_ms = -1.0;  // < 0: every device read the file itself
-    // one job at a time, handed to all workers; generation counters instead of per-call thread creation
+    // job ring: job k lives in slot k % nlanes from submit until its wait returns; lane l of every rank runs the jobs k = l (mod nlanes)
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
-    uint64_t gen = 0;
-    int pending = 0;
+    int64_t submitted = 0;  // jobs handed in so far (tickets 0 .. submitted - 1)
+    int64_t retired = 0;    // every ticket below this has been waited for (its slot is free)
     bool quit = false;
-    Job job;
-    std::mutex call_mu;  // dinov2_hip_group_predict is not re-entrant on one group
+    std::vector<Job> ring;
+    std::mutex call_mu;  // serialises dinov2_hip_group_predict callers (submit + wait as one unit)
 };
 
 namespace {
@@ -120,15 +148,32 @@ void shard_range(int B, int G, int r, int* lo, int* hi) {
     *hi = *lo + q + (r < rem ? 1 : 0);
 }
 
-// the worker's share of one group predict: pointers advanced to the shard offset, then the ordinary single-device entry point
-void run_shard(dinov2_hip_group* g, int r, const Job& job) {
+// Rank r's share of job `k` (a copy of the caller's descriptors), run by lane k % nlanes: the shard's images to the lane's
+// staging buffer, the forward on device-resident input, the results to the caller's buffers at the shard offset -- each step behind
+// the device's turnstile for it, so the steps of consecutive jobs overlap across lanes but never reorder.
+void run_job(dinov2_hip_group* g, int r, int l, int64_t k, const Job& job, int* rc_out, char* err, size_t errlen) {
     auto& rk = *g->ranks[(size_t)r];
-    rk.rc = DINOV2_HIP_OK;
-    rk.err[0] = 0;
-    const dinov2_hip_input& in = *job.in;
+    auto& ln = *rk.lanes[(size_t)l];
+    *rc_out = DINOV2_HIP_OK;
+    auto enter = [&](int t) {
+        std::unique_lock<std::mutex> lk(rk.turn_mu);
+        rk.turn_cv.wait(lk, [&] { return rk.turn[t] == k; });
+    };
+    auto leave = [&](int t) {
+        std::lock_guard<std::mutex> lk(rk.turn_mu);
+        rk.turn[t] = k + 1;
+        rk.turn_cv.notify_all();
+    };
+    const dinov2_hip_input& in = job.in;
     int lo, hi;
     shard_range(in.batch, (int)g->ranks.size(), r, &lo, &hi);
-    if (hi <= lo) return;
+    if (hi <= lo) {  // B < G: nothing for this device, but the turnstiles still turn
+        for (int t = 0; t < 3; ++t) {
+            enter(t);
+            leave(t);
+        }
+        return;
+    }
     const dinov2_hip_hparams& hp = rk.model->hp;
     const bool classify = (job.flags & DINOV2_HIP_CLASSIFY) != 0;
     const bool raw = in.layout == DINOV2_HIP_U8_BGR_HWC;
@@ -138,12 +183,32 @@ void run_shard(dinov2_hip_group* g, int r, const Job& job) {
     const size_t H = hp.hidden_size, C = hp.num_classes;
     const size_t P = (size_t)(h / (int)hp.patch_size) * (w / (int)hp.patch_size);
     const size_t tok_rows = P + (classify ? hp.num_register_tokens : 0);
+    const size_t nbytes = (size_t)(hi - lo) * in_stride;
+    const char* src = reinterpret_cast<const char*>(in.data) + (size_t)lo * in_stride;
+
+    // ---- turnstile 0: host -> device (the lane's previous job has been fetched, so its staging buffer is free)
+    enter(0);
+    bool staged = true;
+    if (nbytes > ln.stage_bytes) {
+        if (ln.stage) (void)hipFree(ln.stage);
+        ln.stage = nullptr;
+        ln.stage_bytes = 0;
+        if (hipMalloc(&ln.stage, nbytes) == hipSuccess) ln.stage_bytes = nbytes; else staged = false;
+    }
+    if (staged && (hipMemcpyAsync(ln.stage, src, nbytes, hipMemcpyHostToDevice, ln.stream) != hipSuccess ||
+                   hipStreamSynchronize(ln.stream) != hipSuccess)) {
+        (void)hipGetLastError();
+        staged = false;  // (no staging memory: the session copies the images itself, inside turnstile 1)
+    }
+    leave(0);
+
     dinov2_hip_input si = in;
-    si.data = reinterpret_cast<const float*>(reinterpret_cast<const char*>(in.data) + (size_t)lo * in_stride);
+    si.data = reinterpret_cast<const float*>(staged ? (const char*)ln.stage : src);
+    si.on_device = staged ? 1 : 0;
     si.batch = hi - lo;
     dinov2_hip_output so{};
-    if (job.out) {
-        so = *job.out;
+    if (job.has_out) {
+        so = job.out;
         if (so.cls) so.cls += (size_t)lo * H;
         if (so.patch_tokens) so.patch_tokens += (size_t)lo * tok_rows * H;
         if (so.logits) so.logits += (size_t)lo * C;
@@ -151,26 +216,42 @@ void run_shard(dinov2_hip_group* g, int r, const Job& job) {
         if (so.topk_ids) so.topk_ids += (size_t)lo * (size_t)so.topk;
         if (so.topk_probs) so.topk_probs += (size_t)lo * (size_t)so.topk;
     }
-    rk.rc = dinov2_hip_predict(rk.session, &si, job.out ? &so : nullptr, job.flags, rk.err, sizeof rk.err);
-    if (rk.rc == DINOV2_HIP_OK && (!job.out || job.out->on_device)) rk.rc = dinov2_hip_session_sync(rk.session);
+    // ---- turnstile 1: the forward, results left in the session's workspace
+    enter(1);
+    int rc = dinov2_hip_predict(ln.session, &si, nullptr, job.flags, err, errlen);
+    if (rc == DINOV2_HIP_OK) rc = dinov2_hip_session_sync(ln.session);
+    // an over-long shard was computed in passes (> 2^31-byte activations): its results must leave pass by pass, inside this turnstile
+    const bool refetch = rc == DINOV2_HIP_OK && job.has_out && ln.session->last_b != si.batch;
+    if (refetch) rc = dinov2_hip_predict(ln.session, &si, &so, job.flags, err, errlen);
+    leave(1);
+    // ---- turnstile 2: device -> host, under the next job's forward on the other lane
+    enter(2);
+    if (rc == DINOV2_HIP_OK && job.has_out && !refetch) rc = dinov2_hip_fetch(ln.session, &so, err, errlen);
+    leave(2);
+    *rc_out = rc;
 }
 
-void worker(dinov2_hip_group* g, int r) {
+void worker(dinov2_hip_group* g, int r, int l) {
     (void)hipSetDevice(g->ranks[(size_t)r]->device);
-    uint64_t seen = 0;
-    for (;;) {
+    for (int64_t k = l;; k += g->nlanes) {
         Job job;
         {
             std::unique_lock<std::mutex> lk(g->mu);
-            g->cv_job.wait(lk, [&] { return g->quit || g->gen != seen; });
+            g->cv_job.wait(lk, [&] { return g->quit || g->submitted > k; });
             if (g->quit) return;
-            seen = g->gen;
-            job = g->job;
+            job = g->ring[(size_t)(k % g->nlanes)];
         }
-        run_shard(g, r, job);
+        int rc = 0;
+        char err[256] = {0};
+        run_job(g, r, l, k, job, &rc, err, sizeof err);
         {
             std::lock_guard<std::mutex> lk(g->mu);
-            if (--g->pending == 0) g->cv_done.notify_all();
+            Job& slot = g->ring[(size_t)(k % g->nlanes)];
+            if (rc != DINOV2_HIP_OK && slot.rc == DINOV2_HIP_OK) {
+                slot.rc = rc;
+                snprintf(slot.err, sizeof slot.err, "device %d: %s", g->ranks[(size_t)r]->device, err[0] ? err : "predict failed");
+            }
+            if (--slot.remaining == 0) g->cv_done.notify_all();
         }
     }
 }
@@ -184,6 +265,7 @@ extern "C" void dinov2_hip_default_group_opts(dinov2_hip_group_opts* o) {
     o->n_devices = 0;
     o->devices = nullptr;
     o->broadcast = 1;
+    o->streams_per_device = 2;
 }
 
 extern "C" void dinov2_hip_group_free(dinov2_hip_group* g) {
@@ -194,9 +276,15 @@ extern "C" void dinov2_hip_group_free(dinov2_hip_group* g) {
     }
     g->cv_job.notify_all();
     for (auto& rk : g->ranks)
-        if (rk->th.joinable()) rk->th.join();
+        for (auto& ln : rk->lanes)
+            if (ln->th.joinable()) ln->th.join();
     for (auto& rk : g->ranks) {
-        if (rk->session) dinov2_hip_session_free(rk->session);
+        (void)hipSetDevice(rk->device);
+        for (auto& ln : rk->lanes) {
+            if (ln->session) dinov2_hip_session_free(ln->session);  // (synchronises the lane's stream first)
+            if (ln->stage) (void)hipFree(ln->stage);
+            if (ln->stream) (void)hipStreamDestroy(ln->stream);
+        }
         if (rk->model) dinov2_hip_model_free(rk->model);
     }
     delete g;
@@ -309,11 +397,24 @@ extern "C" int dinov2_hip_group_create(const char* gguf_path, const dinov2_hip_g
             return DINOV2_HIP_ERR_HIP;
         }
     }
+    g->nlanes = o.streams_per_device <= 0 ? 2 : o.streams_per_device > 4 ? 4 : o.streams_per_device;
+    g->ring.resize((size_t)g->nlanes);
     for (auto& rk : g->ranks) {
-        const int rc = dinov2_hip_session_create(rk->model, nullptr, &rk->session, err, errlen);
-        if (rc != DINOV2_HIP_OK) return rc;
+        HIPG_TRY(hipSetDevice(rk->device));
+        int least = 0, greatest = 0;  // numerically lower = higher priority
+        HIPG_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int l = 0; l < g->nlanes; ++l) {
+            std::unique_ptr<dinov2_hip_group::Lane> ln(new dinov2_hip_group::Lane());
+            (void)least;
+            HIPG_TRY(hipStreamCreateWithPriority(&ln->stream, hipStreamNonBlocking, greatest));
+            rk->lanes.push_back(std::move(ln));
+            auto& lane = *rk->lanes.back();
+            const int rc = dinov2_hip_session_create(rk->model, (void*)lane.stream, &lane.session, err, errlen);
+            if (rc != DINOV2_HIP_OK) return rc;
+        }
     }
-    for (size_t i = 0; i < g->ranks.size(); ++i) g->ranks[i]->th = std::thread(worker, g.get(), (int)i);
+    for (size_t i = 0; i < g->ranks.size(); ++i)
+        for (int l = 0; l < g->nlanes; ++l) g->ranks[i]->lanes[(size_t)l]->th = std::thread(worker, g.get(), (int)i, l);
     *out = g.release();
     return DINOV2_HIP_OK;
 }
@@ -326,10 +427,10 @@ extern "C" dinov2_hip_model* dinov2_hip_group_model(dinov2_hip_group* g, int32_t
 
 extern "C" double dinov2_hip_group_broadcast_ms(const dinov2_hip_group* g) { return g ? g->broadcast_ms : -1.0; }
 
-extern "C" int dinov2_hip_group_predict(dinov2_hip_group* g, const dinov2_hip_input* in, dinov2_hip_output* out, uint32_t flags,
-                                        char* err, size_t errlen) {
-    if (!g || !in || !in->data || in->batch <= 0) {
-        set_err(err, errlen, "null group / input");
+extern "C" int dinov2_hip_group_submit(dinov2_hip_group* g, const dinov2_hip_input* in, const dinov2_hip_output* out, uint32_t flags,
+                                       int64_t* ticket, char* err, size_t errlen) {
+    if (!g || !in || !in->data || in->batch <= 0 || !ticket) {
+        set_err(err, errlen, "null group / input / ticket");
         return DINOV2_HIP_ERR_INVALID;
     }
     if (in->on_device || (out && out->on_device)) {
@@ -337,22 +438,50 @@ extern "C" int dinov2_hip_group_predict(dinov2_hip_group* g, const dinov2_hip_in
         set_err(err, errlen, "group predict takes host buffers (each device copies its own shard)");
         return DINOV2_HIP_ERR_INVALID;
     }
-    std::lock_guard<std::mutex> call(g->call_mu);
-    {
-        std::lock_guard<std::mutex> lk(g->mu);
-        g->job = Job{in, out, flags};
-        g->pending = (int)g->ranks.size();
-        ++g->gen;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (g->submitted - g->retired >= g->nlanes) {
+        set_err(err, errlen, "%d jobs already in flight (streams_per_device): wait for one first", g->nlanes);
+        return DINOV2_HIP_ERR_INVALID;
     }
+    const int64_t k = g->submitted;
+    Job& slot = g->ring[(size_t)(k % g->nlanes)];
+    slot = Job{};
+    slot.in = *in;
+    if (out) slot.out = *out;
+    slot.has_out = out != nullptr;
+    slot.flags = flags;
+    slot.remaining = (int)g->ranks.size();
+    ++g->submitted;
+    *ticket = k;
+    lk.unlock();
     g->cv_job.notify_all();
-    {
-        std::unique_lock<std::mutex> lk(g->mu);
-        g->cv_done.wait(lk, [&] { return g->pending == 0; });
-    }
-    for (auto& rk : g->ranks)
-        if (rk->rc != DINOV2_HIP_OK) {
-            set_err(err, errlen, "device %d: %s", rk->device, rk->err[0] ? rk->err : "predict failed");
-            return rk->rc;
-        }
     return DINOV2_HIP_OK;
+}
+
+extern "C" int dinov2_hip_group_wait(dinov2_hip_group* g, int64_t ticket, char* err, size_t errlen) {
+    if (!g) return DINOV2_HIP_ERR_INVALID;
+    std::unique_lock<std::mutex> lk(g->mu);
+    if (ticket != g->retired || ticket >= g->submitted) {  // in submission order: results land in the order the images came in
+        set_err(err, errlen, "wait for tickets in submission order (next: %lld)", (long long)g->retired);
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    Job& slot = g->ring[(size_t)(ticket % g->nlanes)];
+    g->cv_done.wait(lk, [&] { return slot.remaining == 0; });
+    const int rc = slot.rc;
+    if (rc != DINOV2_HIP_OK) set_err(err, errlen, "%s", slot.err);
+    ++g->retired;
+    return rc;
+}
+
+extern "C" int dinov2_hip_group_predict(dinov2_hip_group* g, const dinov2_hip_input* in, dinov2_hip_output* out, uint32_t flags,
+                                        char* err, size_t errlen) {
+    if (!g) {
+        set_err(err, errlen, "null group");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    std::lock_guard<std::mutex> call(g->call_mu);
+    int64_t t = 0;
+    const int rc = dinov2_hip_group_submit(g, in, out, flags, &t, err, errlen);
+    if (rc != DINOV2_HIP_OK) return rc;
+    return dinov2_hip_group_wait(g, t, err, errlen);
 }

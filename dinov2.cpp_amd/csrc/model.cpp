@@ -155,6 +155,19 @@ extern "C" void dinov2_hip_default_load_opts(dinov2_hip_load_opts* o) {
 
 extern "C" int dinov2_hip_abi_version(void) { return DINOV2_HIP_ABI_VERSION; }
 
+extern "C" void* dinov2_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void dinov2_hip_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opts* opts_in, dinov2_hip_model** out,
                                      char* err, size_t errlen) {
     if (!path || !out) {
@@ -747,6 +760,54 @@ int forward_maybe_graph(dinov2_hip_session* s, const float* img, int B, int h, i
     return DINOV2_HIP_OK;
 }
 
+// Copy-out of the session's last forward (shape in s->last_*): the tail of dino_predict (dinov2.cpp:950-999).
+int fetch_outputs(dinov2_hip_session* s, dinov2_hip_output* out, char* err, size_t errlen) {
+    const dinov2_hip_model* m = s->model;
+    const int B = s->last_b, h = s->last_h, w = s->last_w;
+    const bool classify = s->last_classify;
+    hipStream_t st = s->stream;
+    const Dims d = dims_of(m, B, h, w);
+    const size_t H = m->hp.hidden_size, C = m->hp.num_classes;
+    const int R = (int)m->hp.num_register_tokens;
+    const hipMemcpyKind kind = out->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t pitch = sizeof(float) * (size_t)d.T * H;
+    if (out->cls)  // "cls_token" = final-LN row 0 (dinov2.cpp:764-768)
+        HIP_TRY(hipMemcpy2DAsync(out->cls, sizeof(float) * H, s->fin, pitch, sizeof(float) * H, (size_t)B, kind, st));
+    if (out->patch_tokens) {  // rows [1+R, T) for features, [1, T) when classifying (dinov2.cpp:770-789)
+        const int first = classify ? 1 : 1 + R;
+        const size_t wbytes = sizeof(float) * (size_t)(d.T - first) * H;
+        HIP_TRY(hipMemcpy2DAsync(out->patch_tokens, wbytes, s->fin + (size_t)first * H, pitch, wbytes, (size_t)B, kind, st));
+    }
+    if (classify) {
+        if (out->logits) HIP_TRY(hipMemcpyAsync(out->logits, s->logits, sizeof(float) * B * C, kind, st));
+        if (out->probs) HIP_TRY(hipMemcpyAsync(out->probs, s->probs, sizeof(float) * B * C, kind, st));
+    }
+    if (out->on_device) return DINOV2_HIP_OK;
+
+    std::vector<float> probs_host;
+    const bool want_topk = classify && out->topk > 0 && (out->topk_ids || out->topk_probs);
+    if (want_topk) {
+        probs_host.resize((size_t)B * C);
+        HIP_TRY(hipMemcpyAsync(probs_host.data(), s->probs, sizeof(float) * B * C, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (want_topk) {  // descending sort of all classes like dinov2.cpp:961-965, ids and probabilities returned
+        const int k = std::min<int>(out->topk, (int)C);
+        std::vector<int> idx(C);
+        for (int b = 0; b < B; ++b) {
+            const float* p = probs_host.data() + (size_t)b * C;
+            std::iota(idx.begin(), idx.end(), 0);
+            std::partial_sort(idx.begin(), idx.begin() + k, idx.end(),
+                              [&](int a, int c2) { return p[a] > p[c2] || (p[a] == p[c2] && a < c2); });
+            for (int i = 0; i < out->topk; ++i) {
+                if (out->topk_ids) out->topk_ids[(size_t)b * out->topk + i] = i < k ? idx[(size_t)i] : -1;
+                if (out->topk_probs) out->topk_probs[(size_t)b * out->topk + i] = i < k ? p[idx[(size_t)i]] : 0.f;
+            }
+        }
+    }
+    return DINOV2_HIP_OK;
+}
+
 }  // namespace
 
 extern "C" int dinov2_hip_session_create(dinov2_hip_model* m, void* stream, dinov2_hip_session** out, char* err,
@@ -884,6 +945,7 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
                 rc = dinov2_hip_predict(s, &ci, out ? &co : nullptr, flags, err, errlen);
                 if (rc != DINOV2_HIP_OK) return rc;
             }
+            s->last_b = 0;  // the workspace holds chunk 0 only: nothing for dinov2_hip_fetch
             return DINOV2_HIP_OK;
         }
     }
@@ -923,48 +985,29 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
         s->last_first = classify ? 1 : 1 + (int)m->hp.num_register_tokens;
         s->last_patches = dd.T - s->last_first;
     }
+    s->last_b = B;
+    s->last_h = h;
+    s->last_w = w;
+    s->last_classify = classify;
     if (!out) return DINOV2_HIP_OK;
+    return fetch_outputs(s, out, err, errlen);
+}
 
-    const Dims d = dims_of(m, B, h, w);
-    const size_t H = m->hp.hidden_size, C = m->hp.num_classes;
-    const int R = (int)m->hp.num_register_tokens;
-    const hipMemcpyKind kind = out->on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    const size_t pitch = sizeof(float) * (size_t)d.T * H;
-    if (out->cls)  // "cls_token" = final-LN row 0 (dinov2.cpp:764-768)
-        HIP_TRY(hipMemcpy2DAsync(out->cls, sizeof(float) * H, s->fin, pitch, sizeof(float) * H, (size_t)B, kind, st));
-    if (out->patch_tokens) {  // rows [1+R, T) for features, [1, T) when classifying (dinov2.cpp:770-789)
-        const int first = classify ? 1 : 1 + R;
-        const size_t wbytes = sizeof(float) * (size_t)(d.T - first) * H;
-        HIP_TRY(hipMemcpy2DAsync(out->patch_tokens, wbytes, s->fin + (size_t)first * H, pitch, wbytes, (size_t)B, kind, st));
+extern "C" int dinov2_hip_fetch(dinov2_hip_session* s, dinov2_hip_output* out, char* err, size_t errlen) {
+    if (!s || !out) {
+        set_err(err, errlen, "null session / output");
+        return DINOV2_HIP_ERR_INVALID;
     }
-    if (classify) {
-        if (out->logits) HIP_TRY(hipMemcpyAsync(out->logits, s->logits, sizeof(float) * B * C, kind, st));
-        if (out->probs) HIP_TRY(hipMemcpyAsync(out->probs, s->probs, sizeof(float) * B * C, kind, st));
+    if (s->last_b <= 0) {
+        set_err(err, errlen, "no forward to fetch from (no predict yet, or the last one was split into passes: pass outputs to predict)");
+        return DINOV2_HIP_ERR_INVALID;
     }
-    if (out->on_device) return DINOV2_HIP_OK;
-
-    std::vector<float> probs_host;
-    const bool want_topk = classify && out->topk > 0 && (out->topk_ids || out->topk_probs);
-    if (want_topk) {
-        probs_host.resize((size_t)B * C);
-        HIP_TRY(hipMemcpyAsync(probs_host.data(), s->probs, sizeof(float) * B * C, hipMemcpyDeviceToHost, st));
+    if (out->on_device && (out->topk_ids || out->topk_probs)) {
+        set_err(err, errlen, "top-k outputs are host-only");
+        return DINOV2_HIP_ERR_INVALID;
     }
-    HIP_TRY(hipStreamSynchronize(st));
-    if (want_topk) {  // descending sort of all classes like dinov2.cpp:961-965, ids and probabilities returned
-        const int k = std::min<int>(out->topk, (int)C);
-        std::vector<int> idx(C);
-        for (int b = 0; b < B; ++b) {
-            const float* p = probs_host.data() + (size_t)b * C;
-            std::iota(idx.begin(), idx.end(), 0);
-            std::partial_sort(idx.begin(), idx.begin() + k, idx.end(),
-                              [&](int a, int c2) { return p[a] > p[c2] || (p[a] == p[c2] && a < c2); });
-            for (int i = 0; i < out->topk; ++i) {
-                if (out->topk_ids) out->topk_ids[(size_t)b * out->topk + i] = i < k ? idx[(size_t)i] : -1;
-                if (out->topk_probs) out->topk_probs[(size_t)b * out->topk + i] = i < k ? p[idx[(size_t)i]] : 0.f;
-            }
-        }
-    }
-    return DINOV2_HIP_OK;
+    HIP_TRY(hipSetDevice(s->model->device));
+    return fetch_outputs(s, out, err, errlen);
 }
 
 extern "C" int dinov2_hip_debug_hidden(dinov2_hip_session* s, const dinov2_hip_input* in, int32_t layer, float* out,

@@ -53,6 +53,8 @@ struct dinov2_hip_session {
     size_t raw_bytes = 0;
     char* pca_buf = nullptr;  // dinov2_hip_pca3's device scratch, grown on demand
     size_t pca_bytes = 0;
+    int last_b = 0, last_h = 0, last_w = 0;  // shape of the last un-split forward (0: none): what dinov2_hip_fetch copies out
+    bool last_classify = false;
     int last_first = 0, last_patches = 0;  // rows [last_first, last_first + last_patches) of image 0 in `fin`: its patch tokens
     // carved views (valid for cur_* shape)
     int cur_b = 0, cur_h = 0, cur_w = 0;

@@ -137,8 +137,14 @@ void *dinov2_hip_session_stream(dinov2_hip_session *session);
 int dinov2_hip_predict(dinov2_hip_session *session, const dinov2_hip_input *in, dinov2_hip_output *out,
                        uint32_t flags, char *err, size_t errlen);
 
+/* Copy-out half of dinov2_hip_predict on its own: the outputs of the session's LAST predict (which may have been called with
+ * out = NULL, i.e. forward only) into the caller's buffers.  Lets a host overlap the device -> host copy of batch k with the
+ * forward of batch k + 1 on another session (this is what the group's lanes do).  Not available after a predict that had to
+ * split an over-long batch into passes. */
+int dinov2_hip_fetch(dinov2_hip_session *session, dinov2_hip_output *out, char *err, size_t errlen);
+
 /* -- multi-device group (no reference counterpart: the reference is one backend, batch 1) -----------------
- *    One host thread + one session per device inside the library; dinov2_hip_group_predict splits the caller's global batch
+ *    Host threads + sessions per device inside the library; dinov2_hip_group_predict splits the caller's global batch
  *    contiguously (device g owns images [g*B/G, (g+1)*B/G), remainder to the low ranks) and every device writes its results
  *    into the caller's HOST buffers at its shard offset.  Images are independent forwards: no data-path collective.  With
  *    `broadcast` = 1 (default) only device 0 parses / dequantises the GGUF; the packed weight arena reaches the others by ONE
@@ -150,7 +156,9 @@ typedef struct dinov2_hip_group_opts {
     int32_t n_devices;         /* 0: every visible device                                                                     */
     const int32_t *devices;    /* [n_devices] HIP ordinals, or NULL for 0 .. n_devices-1                                      */
     int32_t broadcast;         /* 1: rank 0 loads, RCCL broadcast of the arena; 0: every rank loads the file                  */
-    int32_t reserved[8];
+    int32_t streams_per_device; /* lanes (host thread + stream + workspace) per device, 1..4; default 2 = the number of jobs
+                                   dinov2_hip_group_submit accepts before one must be waited for.  Results do not depend on it. */
+    int32_t reserved[7];
 } dinov2_hip_group_opts;
 void dinov2_hip_default_group_opts(dinov2_hip_group_opts *opts);
 int dinov2_hip_group_create(const char *gguf_path, const dinov2_hip_group_opts *opts, dinov2_hip_group **out, char *err,
@@ -165,6 +173,21 @@ double dinov2_hip_group_broadcast_ms(const dinov2_hip_group *group);
  * shard has landed.  B < G leaves the high ranks idle.  One call at a time per group. */
 int dinov2_hip_group_predict(dinov2_hip_group *group, const dinov2_hip_input *in, dinov2_hip_output *out, uint32_t flags,
                              char *err, size_t errlen);
+/* The same call in two halves, so that ONE host thread can keep up to `streams_per_device` batches in flight: while a device
+ * computes batch k, its other lane copies batch k + 1 in and batch k - 1 out (host -> device copy, forward and device -> host
+ * copy are separate turnstiles per device, each passed in submission order).  `in` / `out` are copied; the buffers they point
+ * to must stay valid (and unread) until the ticket has been waited for.  Tickets are waited for in submission order.  Results
+ * are bit-identical to dinov2_hip_group_predict's.  Page-locked buffers (dinov2_hip_host_alloc) make the copies faster but are
+ * not required. */
+int dinov2_hip_group_submit(dinov2_hip_group *group, const dinov2_hip_input *in, const dinov2_hip_output *out, uint32_t flags,
+                            int64_t *ticket, char *err, size_t errlen);
+int dinov2_hip_group_wait(dinov2_hip_group *group, int64_t ticket, char *err, size_t errlen);
+
+/* Page-locked host memory for images / results handed to dinov2_hip_predict or dinov2_hip_group_predict: copies to and from
+ * such buffers run at the full PCIe rate and truly asynchronously (pageable memory is staged through bounce buffers by the
+ * runtime, at roughly half the rate).  Plain malloc'ed buffers remain valid inputs.  NULL on failure. */
+void *dinov2_hip_host_alloc(size_t bytes);
+void dinov2_hip_host_free(void *ptr);
 
 /* -- preprocessing (replaces dino_preprocess / dino_classify_preprocess, dinov2.h:93-96,
  *    dinov2.cpp:106-156, without OpenCV).  mode 0: resize to ((w/p)+1)*p x ((h/p)+1)*p; mode 1: resize to 256x256 ignoring

@@ -69,6 +69,66 @@ def test_group_vit_l_shapes_equal_single_session(api, pkg, tmp_path):
     assert np.abs(lo["logits"] - ref["logits"]).max() <= 1e-3 * max(1.0, np.abs(ref["logits"]).max())
 
 
+def test_group_pipelined_jobs_equal_plain_predict(api, golden_dir):
+    """dinov2_hip_group_submit / _wait with streams_per_device = 1, 2, 3 jobs in flight (copy-in, forward and copy-out of
+    consecutive batches overlapping across a device's lanes), pageable and page-locked host buffers, ragged batches incl. B <
+    devices, classify and features: every output bit for bit what a plain single-session predict returns; the in-flight limit
+    and the wait order are enforced."""
+    gguf = os.path.join(golden_dir, "tiny_swiglu_reg4.gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    rng = np.random.default_rng(3)
+    batches = [rng.standard_normal((b, 3, 84, 70)).astype(np.float32) for b in (9, 5, 1, 4, 7, 2)]
+    pinned = []
+    for x in batches:
+        p = api.pinned_empty(x.shape, np.float32)
+        p[...] = x
+        pinned.append(p)
+    for lanes in (1, 2, 3):
+        grp = api.Group(gguf, devices=[0, 0], classify=True, streams_per_device=lanes)
+        for classify in (True, False):
+            refs = [sess.predict(x, classify=classify, topk=2 if classify else 0) for x in batches]
+            for src in (batches, pinned):
+                inflight, got = [], []
+                for x in src:
+                    if len(inflight) == lanes:
+                        got.append(grp.wait(inflight.pop(0)))
+                    inflight.append(grp.submit(x, classify=classify, topk=2 if classify else 0))
+                while inflight:
+                    got.append(grp.wait(inflight.pop(0)))
+                for r, o in zip(refs, got):
+                    assert r.keys() == o.keys()
+                    for k in r:
+                        assert np.array_equal(r[k], o[k]), (lanes, classify, k)
+        hs = [grp.submit(batches[0], classify=True) for _ in range(lanes)]
+        with pytest.raises(api.DinoError):  # lanes + 1 jobs in flight
+            grp.submit(batches[0], classify=True)
+        if lanes > 1:
+            with pytest.raises(api.DinoError):  # out of order
+                grp.wait(hs[1])
+        for hnd in hs:
+            assert np.array_equal(grp.wait(hnd)["logits"], sess.predict(batches[0], classify=True)["logits"])
+        assert np.array_equal(grp.predict(pinned[1], classify=True)["logits"], sess.predict(batches[1], classify=True)["logits"])
+        grp.close()
+
+
+def test_fetch_after_forward_only_predict(api, golden_dir):
+    """dinov2_hip_fetch: predict with out = NULL (forward only), then the copy-out as its own call -- same bits as the one-call form."""
+    import ctypes as C
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    imgs = np.random.default_rng(5).standard_normal((3, 3, 56, 84)).astype(np.float32)
+    ref = sess.predict(imgs, classify=True, topk=3)
+    L = api.lib()
+    err = C.create_string_buffer(256)
+    out, o = api._alloc_outputs(sess.model.hparams, 3, 56, 84, api.RGB_CHW, True, 3, ("cls", "patch_tokens", "logits", "probs"))
+    assert L.dinov2_hip_fetch(api.Session(sess.model)._h, C.byref(o), err, len(err)) == 4  # nothing to fetch yet
+    i = api.Input(imgs.ctypes.data, 3, 56, 84, api.RGB_CHW, 0)
+    assert L.dinov2_hip_predict(sess._h, C.byref(i), None, api.CLASSIFY, err, len(err)) == 0
+    assert L.dinov2_hip_fetch(sess._h, C.byref(o), err, len(err)) == 0, err.value
+    for k in ref:
+        assert np.array_equal(ref[k], out[k]), k
+
+
 def test_group_rccl_broadcast_one_rank(api, golden_dir):
     """broadcast = 1 with a single device: dlopen(librccl), ncclCommInitAll, the arena broadcast (root to itself) and teardown all
     run; results equal the plain session's."""
