@@ -129,6 +129,53 @@ def test_cpp_inference_end_to_end(golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
+def test_cpp_realtime_loop(golden_dir, tmp_path):
+    """examples/realtime.cpp: the reference's realtime loop (realtime.cpp:56-108) without camera and window -- 854 x 480 frames ->
+    raw-u8 predict (tokens stay on the device) -> dinov2_hip_pca3(tokens = NULL) -> min-max -> 35 x 62 map -> nearest resize ->
+    hconcat.  Builds with plain g++ against the shim; the right half of the written frame is the PCA map the Python helper
+    renders from the same frame's tokens (one grey level of slack: f16-rounded covariance), the left half is the input frame."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "realtime")
+    libdir = os.path.join(root, "dinov2.cpp_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "realtime.cpp"),
+                           "-o", exe, "-L" + libdir, "-ldinov2_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:480, 0:854]
+    rgb = np.stack([(xx * 255 // 854), (yy * 255 // 480), ((xx // 61 + yy // 48) % 2) * 200], -1).astype(np.uint8)
+    rgb = np.clip(rgb.astype(np.int32) + rng.integers(-8, 9, rgb.shape), 0, 255).astype(np.uint8)
+    src, out = str(tmp_path / "frame.ppm"), str(tmp_path / "combined.ppm")
+    with open(src, "wb") as f:
+        f.write(b"P6\n854 480\n255\n" + rgb.tobytes())
+    r = subprocess.run([exe, "-m", gguf, "-n", "4", "-i", src, "-o", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "REALTIME_OK" in r.stdout and r.stderr.count("graph computation took") == 4, r.stdout + r.stderr
+    assert "2170 patches" in r.stdout
+    raw = open(out, "rb").read()
+    hdr = b"P6\n1708 480\n255\n"
+    assert raw.startswith(hdr)
+    comb = np.frombuffer(raw[len(hdr):], np.uint8).reshape(480, 1708, 3)
+    assert np.array_equal(comb[:, :854], rgb)
+    # the same frame through the Python API: features of the raw frame, PCA map at the frame size
+    from __graft_entry__ import load_package, PKG_NAME
+    load_package()
+    from importlib import import_module
+    api = import_module(PKG_NAME + ".api")
+    inf = import_module(PKG_NAME + ".inference")
+    sess = api.Session(api.Model(gguf, classify=False))
+    bgr = np.ascontiguousarray(rgb[:, :, ::-1])
+    tok = sess.predict(bgr[None], classify=False, layout=api.U8_BGR_HWC, want=("patch_tokens",))["patch_tokens"][0]
+    assert tok.shape[0] == 35 * 62
+    ref = inf.pca_visual(tok, 35, 62, 480, 854, session=sess)  # BGR map, like the C++ program's before its PPM swap
+    got_bgr = comb[:, 854:, ::-1]
+    d = np.abs(ref.astype(np.int32) - got_bgr.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() <= 0.05, (int(d.max()), float((d > 0).mean()))
+    # synthetic frames (no -i): the loop runs and reports its rates
+    r = subprocess.run([exe, "-m", gguf, "-n", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "frames/s" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
 def test_pca_visual_device_matches_host(golden_dir):
     """pca_visual with a session (device covariance) against the numpy path on structured tokens: same picture up to one grey
     level (the covariance is accumulated from f16-rounded centred tokens)."""
