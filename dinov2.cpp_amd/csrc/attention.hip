@@ -79,6 +79,28 @@ static __device__ __forceinline__ f32x16 mfma32_c(V8 a, V8 b, const f32x16& c) {
     return d;
 }
 
+// Score-chain MFMAs of the 512-register kernel, as asm with the register CLASSES spelled out: a kernel that may need AGPRs makes
+// hipcc select the accumulator form of every MFMA builtin (D / C in AGPRs), so the scores would come out in AGPRs and every one of
+// them would be moved to a VGPR again for the softmax (v_accvgpr_read: ~230 extra VALU operations per key tile, measured in the
+// ISA).  Here D / C are architectural VGPRs (D and C share one class bit, so the -m_run tuple is a VGPR too), while the K fragment
+// (A) and Q^T (B) sit in AGPRs, which only the matrix core (and, for the fragments, the LDS unit) touches.  Hazards as mfma32_c.
+template <typename V8>
+static __device__ __forceinline__ f32x16 mfma32_first_av(V8 a, V8 b, const f32x16& c) {
+    f32x16 d;
+    if constexpr (__is_same(V8, f16x8))
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "a"(a), "a"(b), "v"(c));
+    return d;
+}
+template <typename V8>
+static __device__ __forceinline__ void mfma32_acc_av(f32x16& acc, V8 a, V8 b) {
+    if constexpr (__is_same(V8, f16x8))
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "a"(b));
+    else
+        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(a), "a"(b));
+}
+
 // hipcc's hazard recogniser pads an MFMA result -> VALU read with the required wait states only when it can see the reader;
 // the asm v_max3 below is opaque to it, so reading fresh accumulators raced with the matrix pipeline (nondeterministic
 // scores, found by the batch-permutation test).  19 wait states cover a 16-pass MFMA; tied operands order the block after
@@ -375,54 +397,75 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #define DINO_ATT_LSUM 0  // 1: softmax denominators on the matrix core (l += ones x P^T, one extra MFMA per 16 keys).  Sums the
                         // f16-rounded probabilities, so it is NOT bit-identical to attention_kernel: off by default
 #endif
-template <typename T, bool LOG2>
-__global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
+// QB = 32-query blocks per wave, NWV = waves per workgroup.  <1, 4>: the batch-1 kernel (2 waves per SIMD).  <2, 2>: 64 queries per
+// wave, ONE wave per SIMD with the whole 512-entry register file (two 128-query workgroups per CU): every K / V^T fragment read
+// from LDS feeds two MFMAs (half the LDS bytes per MFMA) and the MFMA / softmax overlap happens inside the wave's own instruction
+// stream -- the design profiles/r02_attention_anatomy.md section 4 points to.  Per query the arithmetic is the same instruction
+// sequence in the same order for every (QB, NWV): results are bit-identical (test_attention_kernels_agree_bit_for_bit).
+template <typename T, bool LOG2, int QB = 1, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64, QB == 2 ? 1 : 2) void attention2_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
     constexpr int KT = 64, ROWB = 128, TILEB = KT * ROWB;
     constexpr bool LSUM = DINO_ATT_LSUM != 0;
-    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEB];  // [buf][K|V]
+    constexpr int QW = 32 * QB, WGQ = NWV * QW;  // queries per wave / per workgroup
+    constexpr int SI = 8 / NWV;                  // 8-row staging pieces per wave, for K and for V
+    // K/V ring depth.  Two slots (the batch-1 kernel): a tile is staged one step before its use, and the other waves of the SIMD
+    // cover what is left of its latency.  Three slots (one wave per SIMD: nobody covers anything): a tile is staged TWO steps ahead
+    // and the step begins with a counted wait that leaves the newest tile's loads in flight.
+    constexpr int RD = QB == 2 ? 3 : 2;
+    static_assert(!LSUM || QB == 1, "the matrix-core row sums exist for the single-block kernel only");
+    __shared__ __attribute__((aligned(16))) char smem[RD * 2 * TILEB];  // [slot][K|V]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     DINO_TS_INIT
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nqb = (Ttok + 127) / 128, nhd = H >> 6;
+    const int nqb = (Ttok + WGQ - 1) / WGQ, nhd = H >> 6;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);  // all query blocks of a head on one XCD (see attention_kernel)
     const int qb = lid % nqb, h = (lid / nqb) % nhd, b = lid / (nqb * nhd);
     const int H3 = 3 * H;
     const char* base = (const char*)(qkv + (size_t)b * Ttok * H3);
     const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = qb * 128 + wid * 32 + ql;
-    const int qrc = qrow < Ttok ? qrow : Ttok - 1;
+    const int qrow0 = qb * WGQ + wid * QW + ql;  // + 32 u for query block u of this wave
 
-    vec8 qf[4];
+    vec8 qf[QB][4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const vec8*)(base + ((size_t)qrc * H3 + h * 64 + ks * 16 + hh * 8) * 2);
+    for (int u = 0; u < QB; ++u) {
+        const int qrc = qrow0 + 32 * u < Ttok ? qrow0 + 32 * u : Ttok - 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[u][ks] = *(const vec8*)(base + ((size_t)qrc * H3 + h * 64 + ks * 16 + hh * 8) * 2);
+    }
 
     // staging offsets as in attention_kernel; K runs one tile ahead of V, so each has its own cursor
     const char* kbase = base + ((size_t)h * 64 + H) * 2;
     const unsigned rowb = (unsigned)H3 * 2u, vdelta = (unsigned)H * 2u;
-    unsigned koff[2], voff[2], stmax[2];
+    unsigned koff[SI], voff[SI], stmax[SI];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int r = (j * 4 + wid) * 8 + (lane >> 3);
+    for (int j = 0; j < SI; ++j) {
+        const int r = (j * NWV + wid) * 8 + (lane >> 3);
         const unsigned lc = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         koff[j] = voff[j] = (unsigned)r * rowb + lc;
         stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
     }
     const unsigned vswz = (unsigned)((((wid & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;  // as in attention_kernel
     auto stage_k1 = [&](int buf, int j) {
-        glds16(kbase + (koff[j] < stmax[j] ? koff[j] : stmax[j]), smem + buf * 2 * TILEB + (j * 4 + wid) * 8 * ROWB);
+        glds16(kbase + (koff[j] < stmax[j] ? koff[j] : stmax[j]), smem + buf * 2 * TILEB + (j * NWV + wid) * 8 * ROWB);
         koff[j] += KT * rowb;
     };
     auto stage_v1 = [&](int buf, int j) {
-        glds16(kbase + ((voff[j] < stmax[j] ? voff[j] : stmax[j]) ^ vswz) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * 4 + wid) * 8 * ROWB);
+        glds16(kbase + ((voff[j] < stmax[j] ? voff[j] : stmax[j]) ^ vswz) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * NWV + wid) * 8 * ROWB);
         voff[j] += KT * rowb;
     };
-    auto stage_k = [&](int buf) { stage_k1(buf, 0); stage_k1(buf, 1); };
-    auto stage_v = [&](int buf) { stage_v1(buf, 0); stage_v1(buf, 1); };
+    auto stage_k = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < SI; ++j) stage_k1(buf, j);
+    };
+    auto stage_v = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < SI; ++j) stage_v1(buf, j);
+    };
 
     const int sw = (ql >> 1) & 7;
     int kaddr[4];
@@ -454,13 +497,19 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
     };
     auto ex2 = [](float x) { return (DINO_ATT_ABL & 1) ? x * 0.5f : LOG2 ? __builtin_amdgcn_exp2f(x) : __expf(x); };
 
-    f32x16 o[2], negm, lacc;
+    f32x16 o[QB][2], negm[QB], lacc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = negm[r] = lacc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) lacc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < QB; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[u][0][r] = o[u][1][r] = negm[u][r] = 0.f;
     vec8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = E::from_f32(1.0f);
-    float m_run = 0.f, l_run = 0.f;
+    float m_run[QB], l_run[QB];
+#pragma unroll
+    for (int u = 0; u < QB; ++u) m_run[u] = l_run[u] = 0.f;
     constexpr float THR = LOG2 ? 8.0f : 5.5f;
     const int ntiles = (Ttok + KT - 1) / KT;
 
@@ -472,20 +521,20 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
             for (int r = 0; r < 16; ++r)
                 if (kbase_ + kb * 32 + (r & 3) + 8 * (r >> 2) >= Ttok) s[kb][r] = -INFINITY;
     };
-    // move the softmax reference point when the tile maximum (relative to it) exceeds THR; `s` holds scores - m_run
-    auto rescale = [&](f32x16(&s)[2], float mx, bool first) {
+    // move the softmax reference point of query block u when the tile maximum (relative to it) exceeds THR; `s` holds scores - m_run
+    auto rescale = [&](int u, f32x16(&s)[2], float mx, bool first) {
         const bool need = first || mx > THR;
         if (__any(need)) {
             const float d = need ? mx : 0.f;
             const float alpha = first ? 0.f : ex2(-d);
-            m_run += d;
-            l_run *= alpha;
+            m_run[u] += d;
+            l_run[u] *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                o[0][r] *= alpha;
-                o[1][r] *= alpha;
+                o[u][0][r] *= alpha;
+                o[u][1][r] *= alpha;
                 if (LSUM) lacc[r] *= alpha;
-                negm[r] = -m_run;
+                negm[u][r] = -m_run[u];
                 s[0][r] -= d;
                 s[1][r] -= d;
             }
@@ -499,141 +548,233 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
     // reads may still be outstanding.  Issue order: K0..K3 | group g < 4: K(g+4), V(2g), V(2g+1) | group g >= 4: V(2g), V(2g+1).
     // Before score MFMA g < 4: (3 - g) + 3g younger reads; g >= 4: 2 + the three groups in between = 11, 10, 9, 8.
     // PV MFMA u (V fragment u, read in group u) runs in group u + 4 for u < 4 (three groups in between: 9, 8, 7, 6 younger
-    // reads) and after the groups for u >= 4 (2 * (7 - u)).
+    // reads) and after the groups for u >= 4 (2 * (7 - u)).  The fragment reads do not depend on QB: every fragment feeds the
+    // MFMAs of all QB query blocks.
     const unsigned lds0 = (unsigned)(uintptr_t)(DINO_LDS_AS char*)smem;
     unsigned kad[4], vad[2][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) kad[i] = lds0 + kaddr[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) vad[i >> 1][i & 1] = lds0 + vaddr[i >> 1][i & 1];
-#define DINO_KRD(DST, ADDR, OFF) \
-    if (!(DINO_ATT_ABL & 16)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define DINO_KRD(DST, ADDR, OFF)                                                                             \
+    if (!(DINO_ATT_ABL & 16)) {                                                                              \
+        if constexpr (QB == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(DST) : "v"(ADDR), "n"(OFF)); \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));                \
+    }
 #define DINO_VRD(DST, ADDR, OFF) \
     if (!(DINO_ATT_ABL & 8)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-    auto iter = [&](int jt, f32x16(&cur)[2], f32x16(&nxt)[2], auto mask_tag, auto par_tag) {
+    auto iter = [&](int jt, f32x16(&cur)[QB][2], f32x16(&nxt)[QB][2], auto mask_tag, auto par_tag) {
         constexpr bool MASKNEXT = decltype(mask_tag)::value;
         constexpr int PAR = decltype(par_tag)::value;
-        constexpr int KOFF = ((PAR + 1) & 1) * 2 * TILEB;  // K_{jt+1}
-        constexpr int VOFF = PAR * 2 * TILEB + TILEB;      // V_jt
+        constexpr int KOFF = RD == 2 ? ((PAR + 1) & 1) * 2 * TILEB : 0;  // K_{jt+1}
+        constexpr int VOFF = RD == 2 ? PAR * 2 * TILEB + TILEB : 0;      // V_jt
         DINO_TS(0)
         if (!(DINO_ATT_ABL & 4)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();  // K_{jt+1}, V_jt landed (staged one step ago); buffers of K_jt, V_{jt-1} are free
+            if constexpr (RD == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * SI) : "memory");  // all but the previous step's loads (K_{jt+2}, V_{jt+1})
+            __syncthreads();  // K_{jt+1}, V_jt landed; the slots of K_jt, V_{jt-1} are free
         }
         DINO_TS(1)
-        vec8 kf[8], pf[4];
+        // ring slots of this step: K_{jt+1} / V_jt are read, K_{jt+RD} / V_{jt+RD-1} are staged.  Two slots: compile-time parity,
+        // LDS offsets are immediates.  Three slots: run-time offsets added to the eight fragment address registers.
+        const int kst = RD == 2 ? PAR : jt % 3, vst = RD == 2 ? (PAR + 1) & 1 : (jt + 2) % 3;
+        unsigned kA[4], vA[2][2];
+        {
+            const unsigned ko = RD == 2 ? 0u : (unsigned)(((jt + 1) % 3) * 2 * TILEB), vo = RD == 2 ? 0u : (unsigned)((jt % 3) * 2 * TILEB + TILEB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                kA[i] = kad[i] + ko;
+                vA[i >> 1][i & 1] = vad[i >> 1][i & 1] + vo;
+            }
+        }
+        if constexpr (QB == 2) {
+            // 512-register kernel: the values only the matrix core touches live in the accumulator half of the file for the whole
+            // step (O, Q^T and the K fragments: 128 registers), so that the 256 architectural VGPRs hold the two score tiles, -m_run,
+            // P and the V^T fragments.  Without the pins hipcc shuttles ~230 values per step through v_accvgpr_read / _write.
+#pragma unroll
+            for (int u = 0; u < QB; ++u) {
+                asm volatile("" : "+a"(o[u][0]), "+a"(o[u][1]));
+                asm volatile("" : "+a"(qf[u][0]), "+a"(qf[u][1]), "+a"(qf[u][2]), "+a"(qf[u][3]));
+            }
+        }
+        vec8 kf[8], pf[QB][4];
         s16x4 vl[8], vh[8];
         if (DINO_ATT_ABL & 24) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                kf[i] = qf[i & 3];
+                kf[i] = qf[0][i & 3];
                 vl[i] = vh[i] = __builtin_bit_cast(s16x4, (double)jt);
             }
         }
-        DINO_KRD(kf[0], kad[0], KOFF);
-        DINO_KRD(kf[1], kad[1], KOFF);
-        DINO_KRD(kf[2], kad[2], KOFF);
-        DINO_KRD(kf[3], kad[3], KOFF);
+        DINO_KRD(kf[0], kA[0], KOFF);
+        DINO_KRD(kf[1], kA[1], KOFF);
+        DINO_KRD(kf[2], kA[2], KOFF);
+        DINO_KRD(kf[3], kA[3], KOFF);
         DINO_SB();
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#define DINO_PVMMA(U, WAITN)                                                                                 \
+        float ps[QB][4];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) ps[u][0] = ps[u][1] = ps[u][2] = ps[u][3] = 0.f;
+// One MFMA per micro-slot, its share of the VALU work behind it, a scheduling fence between slots: with ONE wave per SIMD the
+// matrix pipe only stays busy if every MFMA is followed by a few VALU instructions and then the next MFMA -- an in-order wave that
+// meets two MFMAs in a row waits out the first one's 32 cycles without issuing anything (measured: the clumped order of the
+// four-waves-per-SIMD kernels ran this kernel at 40 % matrix-pipe utilisation with all data movement removed).
+#define DINO_PVMMA1(U, UU)                                                                                   \
         {                                                                                                    \
-            asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vl[U]), "+v"(vh[U]) : "n"(WAITN));                   \
             const vec4 lo = __builtin_bit_cast(vec4, vl[U]), hi = __builtin_bit_cast(vec4, vh[U]);           \
             const vec8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);                         \
-            o[(U) & 1] = E::mfma32(vf, pf[(U) >> 1], o[(U) & 1]);                                            \
+            o[UU][(U) & 1] = E::mfma32(vf, pf[UU][(U) >> 1], o[UU][(U) & 1]);                                \
         }
+#define DINO_PVWAIT(U, WAITN) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(vl[U]), "+v"(vh[U]) : "n"(WAITN));
 #define DINO_GROUP(G)                                                                                        \
         {                                                                                                    \
-            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-                const int idx = (G) * 4 + j;                                                                 \
-                const float pv = ex2(cur[idx >> 4][idx & 15]);                                               \
-                cur[idx >> 4][idx & 15] = pv;                                                                \
-                if (!LSUM) ps[j] += pv;                                                                      \
+            if constexpr (QB == 2) asm volatile("s_waitcnt lgkmcnt(%1)" : "+a"(kf[G]) : "n"((G) < 4 ? 3 + 2 * (G) : 15 - (G))); \
+            else asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kf[G]) : "n"((G) < 4 ? 3 + 2 * (G) : 15 - (G))); \
+            _Pragma("unroll") for (int u = 0; u < QB; ++u) {                                                 \
+                if constexpr (QB == 1) nxt[u][(G) >> 2] = E::mfma32(kf[G], qf[u][(G) & 3], ((G) & 3) == 0 ? negm[u] : nxt[u][(G) >> 2]); \
+                else if (((G) & 3) == 0) nxt[u][(G) >> 2] = mfma32_first_av(kf[G], qf[u][0], negm[u]);       \
+                else mfma32_acc_av(nxt[u][(G) >> 2], kf[G], qf[u][(G) & 3]);                                 \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                              \
+                    const int idx = (G) * 4 + j;                                                             \
+                    const float pv = ex2(cur[u][idx >> 4][idx & 15]);                                        \
+                    cur[u][idx >> 4][idx & 15] = pv;                                                         \
+                    if (!LSUM) ps[u][j] += pv;                                                               \
+                }                                                                                            \
+                if (((G) & 1) && (G) < 4) {                                                                  \
+                    _Pragma("unroll") for (int j = 0; j < 8; ++j)                                            \
+                        pf[u][(G) >> 1][j] = E::from_f32(cur[u][(G) >> 2][(((G) >> 1) & 1) * 8 + j]);        \
+                }                                                                                            \
+                DINO_SB();                                                                                   \
             }                                                                                                \
-            DINO_SB();                                                                                       \
-            asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kf[G]) : "n"((G) < 4 ? 3 + 2 * (G) : 15 - (G)));     \
-            nxt[(G) >> 2] = E::mfma32(kf[G], qf[(G) & 3], ((G) & 3) == 0 ? negm : nxt[(G) >> 2]);            \
-            if ((G) & 1) {                                                                                   \
-                _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                \
-                    pf[(G) >> 1][j] = E::from_f32(cur[(G) >> 2][(((G) >> 1) & 1) * 8 + j]);                  \
-                if (LSUM) lacc = E::mfma32(ones, pf[(G) >> 1], lacc);                                        \
+            if ((G) >= 4) {                                                                                  \
+                DINO_PVWAIT(((G) - 4) & 7, 13 - (G))                                                         \
+                _Pragma("unroll") for (int u = 0; u < QB; ++u) {                                             \
+                    DINO_PVMMA1(((G) - 4) & 7, u)                                                            \
+                    if ((G) & 1) {                                                                           \
+                        _Pragma("unroll") for (int j = 0; j < 8; ++j)                                        \
+                            pf[u][(G) >> 1][j] = E::from_f32(cur[u][(G) >> 2][(((G) >> 1) & 1) * 8 + j]);    \
+                    }                                                                                        \
+                    DINO_SB();                                                                               \
+                }                                                                                            \
             }                                                                                                \
-            if ((G) >= 4) DINO_PVMMA(((G) - 4) & 7, 13 - (G))                                                \
-            if (!(DINO_ATT_ABL & 2)) {                                                                       \
-                if ((G) == 0) stage_k1(PAR, 0);            /* K_{jt+2}: the loads go out under the MFMAs */   \
-                if ((G) == 1) stage_k1(PAR, 1);                                                              \
-                if ((G) == 2) stage_v1((PAR + 1) & 1, 0);  /* V_{jt+1} */                                    \
-                if ((G) == 3) stage_v1((PAR + 1) & 1, 1);                                                    \
+            if (LSUM && ((G) & 1)) lacc = E::mfma32(ones, pf[0][(G) >> 1], lacc);                            \
+            if (!(DINO_ATT_ABL & 2)) {  /* K_{jt+RD} and V_{jt+RD-1}: the loads go out under the MFMAs */     \
+                if (SI == 2) {                                                                               \
+                    if ((G) == 0) stage_k1(kst, 0);                                                          \
+                    if ((G) == 1) stage_k1(kst, 1);                                                          \
+                    if ((G) == 2) stage_v1(vst, 0);                                                          \
+                    if ((G) == 3) stage_v1(vst, 1);                                                          \
+                } else {                                                                                     \
+                    if ((G) < 4) stage_k1(kst, (G) & (SI - 1));                                              \
+                    else stage_v1(vst, ((G) - 4) & (SI - 1));                                                \
+                }                                                                                            \
             }                                                                                                \
-            if ((G) < 4) DINO_KRD(kf[((G) + 4) & 7], kad[(G) & 3], KOFF + 4096);                             \
-            DINO_VRD(vl[G], vad[0][(G) & 1], VOFF + ((G) >> 1) * 16 * ROWB);                                 \
-            DINO_VRD(vh[G], vad[1][(G) & 1], VOFF + ((G) >> 1) * 16 * ROWB);                                 \
+            if ((G) < 4) DINO_KRD(kf[((G) + 4) & 7], kA[(G) & 3], KOFF + 4096);                              \
+            DINO_VRD(vl[G], vA[0][(G) & 1], VOFF + ((G) >> 1) * 16 * ROWB);                                  \
+            DINO_VRD(vh[G], vA[1][(G) & 1], VOFF + ((G) >> 1) * 16 * ROWB);                                  \
             DINO_SB();                                                                                       \
         }
         DINO_GROUP(0) DINO_GROUP(1) DINO_GROUP(2) DINO_GROUP(3) DINO_GROUP(4) DINO_GROUP(5) DINO_GROUP(6) DINO_GROUP(7)
 #undef DINO_GROUP
-        if (!LSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        if (!LSUM) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) l_run[u] += (ps[u][0] + ps[u][1]) + (ps[u][2] + ps[u][3]);
+        }
         DINO_TS(2)
-        if constexpr (MASKNEXT) mask_tail(nxt, jt + 1);
+        if constexpr (MASKNEXT) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) mask_tail(nxt[u], jt + 1);
+        }
         // second half of PV (keys 32..63 of the tile) with the maximum of the next tile's scores underneath
-        mfma_settle(nxt);
-        float ma, mb;
+#pragma unroll
+        for (int u = 0; u < QB; ++u) mfma_settle(nxt[u]);
+        float ma[QB], mb[QB];
 #define DINO_PV(U)                                                                                           \
         {                                                                                                    \
-            DINO_PVMMA(U, 14 - 2 * (U))                                                                      \
-            _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                  \
-                const f32x16& n = nxt[((U) - 4) >> 1];                                                       \
-                const int i0 = (((U) - 4) & 1) * 8 + c * 4;                                                  \
-                ma = ((U) == 4 && c == 0) ? max3f(n[0], n[0], n[1]) : max3f(ma, n[i0], n[i0 + 1]);           \
-                mb = ((U) == 4 && c == 0) ? max3f(n[2], n[2], n[3]) : max3f(mb, n[i0 + 2], n[i0 + 3]);       \
+            DINO_PVWAIT(U, 14 - 2 * (U))                                                                     \
+            _Pragma("unroll") for (int u = 0; u < QB; ++u) {                                                 \
+                DINO_PVMMA1(U, u)                                                                            \
+                _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                              \
+                    const f32x16& n = nxt[u][((U) - 4) >> 1];                                                \
+                    const int i0 = (((U) - 4) & 1) * 8 + c * 4;                                              \
+                    ma[u] = ((U) == 4 && c == 0) ? max3f(n[0], n[0], n[1]) : max3f(ma[u], n[i0], n[i0 + 1]); \
+                    mb[u] = ((U) == 4 && c == 0) ? max3f(n[2], n[2], n[3]) : max3f(mb[u], n[i0 + 2], n[i0 + 3]); \
+                }                                                                                            \
+                DINO_SB();                                                                                   \
             }                                                                                                \
-            DINO_SB();                                                                                       \
         }
         DINO_PV(4) DINO_PV(5) DINO_PV(6) DINO_PV(7)
 #undef DINO_PV
-#undef DINO_PVMMA
+#undef DINO_PVMMA1
+#undef DINO_PVWAIT
         DINO_TS(3)
-        rescale(nxt, max_halves(max3f(ma, mb, mb)), false);
+#pragma unroll
+        for (int u = 0; u < QB; ++u) rescale(u, nxt[u], max_halves(max3f(ma[u], mb[u], mb[u])), false);
         DINO_TS(4)
     };
-    auto last = [&](int jt, f32x16(&cur)[2]) {
+    auto last = [&](int jt, f32x16(&cur)[QB][2]) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const char* sV = smem + (jt & 1) * 2 * TILEB + TILEB;
-        float ps[4] = {0.f, 0.f, 0.f, 0.f};
+        const char* sV = smem + (jt % RD) * 2 * TILEB + TILEB;
+        float ps[QB][4];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) ps[u][0] = ps[u][1] = ps[u][2] = ps[u][3] = 0.f;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            vec8 pf;
+            vec8 pf[QB];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float pv = ex2(cur[t >> 1][(t & 1) * 8 + j]);
-                ps[j & 3] += pv;
-                pf[j] = E::from_f32(pv);
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = ex2(cur[u][t >> 1][(t & 1) * 8 + j]);
+                    ps[u][j & 3] += pv;
+                    pf[u][j] = E::from_f32(pv);
+                }
+            if (LSUM) lacc = E::mfma32(ones, pf[0], lacc);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const vec8 vf = read_vt(sV, t, db);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) o[u][db] = E::mfma32(vf, pf[u], o[u][db]);
             }
-            if (LSUM) lacc = E::mfma32(ones, pf, lacc);
-#pragma unroll
-            for (int db = 0; db < 2; ++db) o[db] = E::mfma32(read_vt(sV, t, db), pf, o[db]);
         }
-        if (!LSUM) l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        if (!LSUM) {
+#pragma unroll
+            for (int u = 0; u < QB; ++u) l_run[u] += (ps[u][0] + ps[u][1]) + (ps[u][2] + ps[u][3]);
+        }
     };
 
-    // prologue: K_0, V_0, K_1 in flight; scores of tile 0
+    // prologue: K_0, V_0, K_1 (and, with three slots, V_1, K_2) in flight; scores of tile 0 (needs K_0 only)
     stage_k(0);
     stage_v(0);
     stage_k(1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (RD == 3) {
+        stage_v(1);
+        stage_k(2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * SI) : "memory");  // K_0 (and V_0)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
-    f32x16 sa[2], sb[2];
+    f32x16 sa[QB][2], sb[QB][2];
     {
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                sa[kb] = E::mfma32(*(const vec8*)(smem + kaddr[ks] + kb * 32 * ROWB), qf[ks], ks == 0 ? negm : sa[kb]);
-        if (ntiles == 1) mask_tail(sa, 0);
-        mfma_settle(sa);
-        rescale(sa, max_halves(max32(sa)), true);
+            for (int ks = 0; ks < 4; ++ks) {
+                const vec8 kf0 = *(const vec8*)(smem + kaddr[ks] + kb * 32 * ROWB);
+#pragma unroll
+                for (int u = 0; u < QB; ++u) {
+                    if constexpr (QB == 1) sa[u][kb] = E::mfma32(kf0, qf[u][ks], ks == 0 ? negm[u] : sa[u][kb]);
+                    else if (ks == 0) sa[u][kb] = mfma32_first_av(kf0, qf[u][0], negm[u]);
+                    else mfma32_acc_av(sa[u][kb], kf0, qf[u][ks]);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            if (ntiles == 1) mask_tail(sa[u], 0);
+            mfma_settle(sa[u]);
+            rescale(u, sa[u], max_halves(max32(sa[u])), true);
+        }
     }
     // steps jt = 0 .. ntiles-2 (the last of them masks the tail of its next tile), two per trip so that the score
     // registers swap roles without moves
@@ -658,20 +799,24 @@ __global__ __launch_bounds__(256, 2) void attention2_kernel(const T* __restrict_
 
     DINO_TS(6)
     DINO_TS_FLUSH
-    // with LSUM every element of lacc is the full row sum (both lane halves included)
-    const float l_tot = LSUM ? lacc[0] : l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
-    if (qrow < Ttok) {
-        T* orow = out + ((size_t)b * Ttok + qrow) * H + h * 64;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+    for (int u = 0; u < QB; ++u) {
+        // with LSUM every element of lacc is the full row sum (both lane halves included)
+        const float l_tot = LSUM ? lacc[0] : l_run[u] + __shfl_xor(l_run[u], 32);
+        const float inv = 1.0f / l_tot;
+        const int qrow = qrow0 + 32 * u;
+        if (qrow < Ttok) {
+            T* orow = out + ((size_t)b * Ttok + qrow) * H + h * 64;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                vec4 w;
+            for (int db = 0; db < 2; ++db)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = E::from_f32(o[db][g * 4 + j] * inv);
-                *(vec4*)(orow + db * 32 + g * 8 + hh * 4) = w;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    vec4 w;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = E::from_f32(o[u][db][g * 4 + j] * inv);
+                    *(vec4*)(orow + db * 32 + g * 8 + hh * 4) = w;
+                }
+        }
     }
 }
 #undef DINO_KRD
@@ -725,6 +870,14 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
         if (dt == DT_F16) { if (log2_scores) DINO_ATT2(_Float16, true); else DINO_ATT2(_Float16, false); }
         else { if (log2_scores) DINO_ATT2(__bf16, true); else DINO_ATT2(__bf16, false); }
 #undef DINO_ATT2
+        return hipGetLastError();
+    }
+    if (ver == 4) {  // pipelined, 64 queries per wave, one wave per SIMD, two 128-query workgroups per CU
+        const dim3 grid4(((T + 127) / 128) * nh * B), block4(128);
+#define DINO_ATT4(TT, LG) hipLaunchKernelGGL((attention2_kernel<TT, LG, 2, 2>), grid4, block4, 0, st, (const TT*)qkv, (TT*)out, T, H)
+        if (dt == DT_F16) { if (log2_scores) DINO_ATT4(_Float16, true); else DINO_ATT4(_Float16, false); }
+        else { if (log2_scores) DINO_ATT4(__bf16, true); else DINO_ATT4(__bf16, false); }
+#undef DINO_ATT4
         return hipGetLastError();
     }
     if (ver == 3) {  // 64 queries per wave, NWQ waves per workgroup

@@ -231,15 +231,18 @@ int dinov2_hip_debug_hidden(dinov2_hip_session *session, const dinov2_hip_input 
 int dinov2_hip_abi_version(void);
 
 /* -- Environment ----------------------------------------------------------------------------------------------------------
- * The library reads exactly four environment variables; none is needed in normal use.
+ * The library reads exactly five environment variables; none is needed in normal use.
  *   DINOV2_HIP_GRAPHS=1      replay a captured hipGraph for a forward that repeats with the same session, input pointer, shape
  *                            and flags (second sighting is captured).  Off by default: the forward is kernel-bound and the
  *                            replay measured no faster on an idle host; it is there for hosts whose launch thread is contended.
  *   DINOV2_HIP_MAX_CHUNK=n   testing aid: split a predict call into passes of at most n images (the split that otherwise only
  *                            happens past 2^31 bytes of activations), to exercise that path at small sizes.
- *   DINOV2_HIP_ATTN_V=1|2|3  testing aid: force the throughput / the software-pipelined attention kernel (normally chosen by
- *   DINOV2_HIP_GEMM_TILE=128|256   workgroup count; 3 = the measured, never auto-selected 64-queries-per-wave variant) and the
- *                            small-tile / persistent GEMM (normally chosen by shape): the bit-equality tests of the kernels use them.
+ *   DINOV2_HIP_ATTN_V=1|2|3|4  testing aid: force the throughput / the software-pipelined attention kernel (normally chosen by
+ *   DINOV2_HIP_GEMM_TILE=128|256   workgroup count; 3 and 4 = the measured, never auto-selected 64-queries-per-wave variants: two waves
+ *                            per SIMD, and software-pipelined with one wave per SIMD) and the small-tile / persistent GEMM (normally
+ *                            chosen by shape): the bit-equality tests of the kernels use them.
+ *   DINOV2_HIP_GROUP_REQUIRE_RCCL=1  dinov2_hip_group_create fails when librccl cannot be loaded instead of letting every device
+ *                            read the GGUF itself.
  * (DINOV2_HIP_LIB, read by the Python binding only, points it at another build of this library.) */
 
 #ifdef __cplusplus

@@ -187,8 +187,8 @@ def test_attention_bitwise_repeatable(api):
 
 @pytest.mark.parametrize("T", [1374, 257, 65])
 def test_attention_kernels_agree_bit_for_bit(api, monkeypatch, T):
-    """The attention kernels (1: 32 queries per wave, 2: software-pipelined for few workgroups, 3: 64 queries per wave) are
-    picked by grid size; an image must not change with the batch it travels in, so all are held to identical bits (same
+    """The attention kernels (1: 32 queries per wave, 2: software-pipelined for few workgroups, 3: 64 queries per wave, 4:
+    software-pipelined with 64 queries per wave and one wave per SIMD) are picked by grid size; an image must not change with the batch it travels in, so all are held to identical bits (same
     summation order, same rescale points).  T = 257 and 65 leave the last wave / the second query block of a wave ragged."""
     B, nh = 1, 3
     H = nh * 64
@@ -196,7 +196,7 @@ def test_attention_kernels_agree_bit_for_bit(api, monkeypatch, T):
     qkv = _round(rng.standard_normal((B * T, 3 * H)).astype(np.float32) * 0.6, F16)
     qkv[T // 2, :H] *= 6.0  # a query with large scores: forces reference-point moves in some tiles
     outs = {}
-    for v in ("1", "2", "3"):
+    for v in ("1", "2", "3", "4"):
         monkeypatch.setenv("DINOV2_HIP_ATTN_V", v)
         out = np.zeros((B * T, H), np.float32)
         assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
@@ -204,6 +204,7 @@ def test_attention_kernels_agree_bit_for_bit(api, monkeypatch, T):
     assert np.isfinite(outs["1"]).all()
     assert np.array_equal(outs["1"], outs["2"])
     assert np.array_equal(outs["1"], outs["3"])
+    assert np.array_equal(outs["1"], outs["4"])
 
 
 def test_attention_online_softmax_rescale(api):
