@@ -330,6 +330,8 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3>();
     if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 3, 2>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -425,6 +427,14 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     // (never for the tail of a large launch -- small_only -- or a large batch's last rows would be summed in another order than its first)
     if (a.allow_ksplit && !a.small_only && cfg == 2 && t64 < 256 && a.K >= 1024 && (a.K / 64) % 2 == 0)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3, 2>(epi, a, st);
+    // The same few-tile shapes when the summation order must not depend on the batch size (the default): EIGHT waves on the same
+    // 64 x 128 tile (4 x 2 wave tiles of 16 x 64).  Nothing about the arithmetic changes -- each output's MFMA chain runs over K in the
+    // same order, so the bits are those of every other kernel -- but the serial part of a K step (issuing the workgroup's 24 LDS-DMA
+    // pieces, the fragment reads, the MFMAs) is spread over twice the waves: at M = 1 374 FFN-out 32.9 -> 28.3 us (split-K: 27.1),
+    // attn-out 12.6 -> 11.2 (10.8), ViT-B attn-out 10.6 -> 9.1.  With more tiles per CU (QKV, FFN-in) co-resident workgroups already
+    // overlap each other and the 8-wave tile is slower (17.7 -> 22.5, 20.1 -> 26.2 us): not used there.
+    if (!a.small_only && cfg == 2 && t64 < 256)
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);
     if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
     if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
     return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2, 2>(epi, a, st);
