@@ -365,6 +365,31 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
+    // N not a multiple of 256 (ViT-S: 384, 1 152): the persistent kernel takes the leading multiple of 256 columns, the small-tile
+    // kernel the remaining ones (two launches; every kernel gives a row the same bits, so the cut is invisible in the results).
+    // Only where the persistent part fills the chip; not for the patch / SwiGLU epilogues (row -> token scatter indexed with N,
+    // interleaved column pairs).
+    {
+        const int nrem = a.N % 256, n1 = a.N - nrem;
+        const bool epi_ok = epi == EPI_QKV || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_PLAIN_F32;
+        if (!a.small_only && forced != 128 && nrem != 0 && n1 >= 256 && epi_ok && (a.K / 64) % 2 == 0 &&
+            (long)(n1 / 256) * ((a.M + 191) / 192) >= 192) {
+            const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
+            GemmArgs a1 = a, a2 = a;
+            a1.N = n1;
+            a1.qcols = a.qcols < n1 ? a.qcols : n1;
+            a2.N = nrem;
+            a2.W = (const char*)a.W + (size_t)n1 * ldw_ * 2;
+            a2.bias = a.bias ? a.bias + n1 : nullptr;
+            a2.aux = a.aux ? a.aux + n1 : nullptr;  // (EPI_RESID: LayerScale [N]; unused by the other three)
+            a2.out = (char*)a.out + (size_t)n1 * osz;
+            a2.qcols = a.qcols > n1 ? a.qcols - n1 : 0;
+            a2.small_only = 1;
+            const hipError_t e = launch_gemm(dt, epi, a1, st);
+            if (e != hipSuccess) return e;
+            return launch_gemm(dt, epi, a2, st);
+        }
+    }
     constexpr bool split_ok = true;
     // (the patch-embed epilogue maps row -> (image, patch): no row splits for it)
     const bool is_patch = epi == EPI_PATCH;

@@ -284,7 +284,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 
         if constexpr (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_SWIGLU) {
             // 2-byte outputs: two passes (token halves) of 64 rows x 64 columns (SwiGLU: x 32)
-            const float qs = (EPI == EPI_QKV && n0 < p.qcols) ? p.qscale : 1.0f;  // tiles never straddle q|k|v
+            // per WAVE (64 columns), not per tile: q|k|v boundaries are multiples of the head size 64, but with hidden = 384 they
+            // fall inside a 256-column tile
+            const float qs = (EPI == EPI_QKV && n0 + ww * 64 < p.qcols) ? p.qscale : 1.0f;
             constexpr int BN_ = EPI == EPI_SWIGLU ? 1 : 2;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
