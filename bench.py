@@ -280,7 +280,8 @@ def main():
     # command and committed under profiles/ (a PMC pass cannot run inside the timed process).
     traffic = None
     try:
-        tfile = next(f for f in ("r02_hbm_traffic.json", "r01_hbm_traffic.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        tfile = next(f for f in ("r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", f)))
         tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
         # FFN-in at this shape runs the mixed 256/192-row launch (gemm.hip plan C): one kernel per GEMM
         syms = {"f16": ("gemm2_mixed_kernelIDF16_Li3E", "gemm2_kernelIDF16_Li3E"),
