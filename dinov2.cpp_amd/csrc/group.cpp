@@ -271,7 +271,14 @@ extern "C" void dinov2_hip_default_group_opts(dinov2_hip_group_opts* o) {
 extern "C" void dinov2_hip_group_free(dinov2_hip_group* g) {
     if (!g) return;
     {
-        std::lock_guard<std::mutex> lk(g->mu);
+        // jobs still in flight (submitted, not waited for) run to completion first: a lane that left now would strand the other
+        // lanes of its device at a turnstile
+        std::unique_lock<std::mutex> lk(g->mu);
+        g->cv_done.wait(lk, [&] {
+            for (int64_t k = g->retired; k < g->submitted; ++k)
+                if (g->ring[(size_t)(k % g->nlanes)].remaining != 0) return false;
+            return true;
+        });
         g->quit = true;
     }
     g->cv_job.notify_all();
