@@ -28,7 +28,9 @@ namespace dinov2 {
 // barriers), and at the end group 1 hands its accumulators to group 0 through LDS: result = acc_lo + acc_hi, one extra f32
 // rounding against the un-split sum.  No global traffic, no extra launch, deterministic -- but not the bits of the un-split
 // kernel, so it is used only when the caller allows it (GemmArgs.allow_ksplit; dinov2_hip_load_opts.batch_invariant = 0).
-template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI, int KS = 1>
+// KSUB = 64-wide K sub-tiles per LDS stage (1, or 2 for the few-tile shapes of a small batch: their K loop is a serial chain of
+// wait -> barrier -> issue -> read -> MFMA per stage, and a stage twice as deep halves the number of links; same K order).
+template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI, int KS = 1, int KSUB = 1>
 __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma clang fp contract(off)  // position-independent results: see gemm2.hip
     using E = Elem<T>;
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     constexpr int NW = WM * WN;
     constexpr int BK = 64;
     constexpr int ROWB = BK * 2;  // bytes per LDS row
-    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int SUBT = (BM + BN) * ROWB;  // one 64-wide K sub-tile: A rows, then W rows
+    constexpr int STAGE = KSUB * SUBT;
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int MREP = WTM / 16, NREP = WTN / 16;  // 16 x 16 accumulator blocks of the wave tile (MFMA 16x16x32)
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // glds wave-instructions per wave per tile
@@ -78,15 +81,18 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     }
 
     char* const smem = smem_all + grp * (NST * STAGE);  // this group's LDS ring
-    const int kt_lo = grp * ((K / BK) / KS);            // this group's K range (the launcher guarantees (K / 64) % KS == 0)
+    const int kt_lo = grp * ((K / BK) / KS);            // this group's K range (the launcher guarantees (K / 64) % (KS * KSUB) == 0)
     auto stage = [&](int buf, int kt) {
-        char* sA = smem + buf * STAGE;
-        char* sB = sA + BM * ROWB;
-        const size_t koff = (size_t)(kt_lo + kt) * (BK * 2);
 #pragma unroll
-        for (int j = 0; j < AI; ++j) glds16(asrc[j] + koff, sA + (j * NW + wid) * 8 * ROWB);
+        for (int sb = 0; sb < KSUB; ++sb) {
+            char* sA = smem + buf * STAGE + sb * SUBT;
+            char* sB = sA + BM * ROWB;
+            const size_t koff = (size_t)(kt_lo + kt * KSUB + sb) * (BK * 2);
 #pragma unroll
-        for (int j = 0; j < BI; ++j) glds16(bsrc[j] + koff, sB + (j * NW + wid) * 8 * ROWB);
+            for (int j = 0; j < AI; ++j) glds16(asrc[j] + koff, sA + (j * NW + wid) * 8 * ROWB);
+#pragma unroll
+            for (int j = 0; j < BI; ++j) glds16(bsrc[j] + koff, sB + (j * NW + wid) * 8 * ROWB);
+        }
     };
 
     // ---- fragment read offsets ----
@@ -107,9 +113,9 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     // nothing else hides the global -> LDS latency.  One barrier per K tile: (a) every wave's loads of tile kt have landed
     // (each wave waits for its own with a counted vmcnt -- loads return in order -- before the barrier), (b) every wave is
     // done reading the buffer that tile kt+NST-1 is about to overwrite.  Raw s_barrier: __syncthreads() would drain vmcnt.
-    constexpr int LPT = AI + BI;  // glds instructions per wave per tile
+    constexpr int LPT = KSUB * (AI + BI);  // glds instructions per wave per stage
     static_assert((NST - 2) * LPT < 64, "vmcnt is 6 bits");
-    const int nk = (K / BK) / KS;
+    const int nk = (K / BK) / KS / KSUB;
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
@@ -122,11 +128,13 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPT < 64 ? 3 * LPT : 0) : "memory");
         static_assert(NST <= 5, "extend the vmcnt dispatch above");
         if (kt + NST - 1 < nk) stage(nbuf, kt + NST - 1);
-        const char* s = smem + buf * STAGE;
+        const char* s0 = smem + buf * STAGE;
         nbuf = buf;  // the buffer just consumed is the next to be refilled
         buf = buf + 1 == NST ? 0 : buf + 1;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {  // two k-steps of 32: the K order of gemm2.hip, so both kernels give a row the same bits
+        for (int sk = 0; sk < 2 * KSUB; ++sk) {  // k-steps of 32 in ascending K: the order of gemm2.hip, so both kernels give a row the same bits
+            const char* s = s0 + (sk >> 1) * SUBT;
+            const int ks = sk & 1;
             const int ch = ((ks * 4 + fh) ^ sw) << 4;
             vec8 af[MREP], bf[NREP];
 #pragma unroll
@@ -277,14 +285,14 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1, int KSUB = 1>
 static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
     const dim3 grid(ntn * ntm), block(WM * WN * 64 * KS);
-    const size_t lds = KS * NST * (size_t)(BM + BN) * 128;
+    const size_t lds = KS * NST * KSUB * (size_t)(BM + BN) * 128;
 #define DINO_LAUNCH(E)                                                                             \
     case E:                                                                                        \
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E, KS>), grid, block, lds, st, a);     \
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E, KS, KSUB>), grid, block, lds, st, a); \
         break;
     switch (epi) {
         DINO_LAUNCH(EPI_PATCH)
@@ -298,13 +306,13 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1, int KSUB = 1>
 static hipError_t set_attr_cfg() {
-    const int lds = KS * NST * (BM + BN) * 128;
+    const int lds = KS * NST * KSUB * (BM + BN) * 128;
     hipError_t e = hipSuccess;
 #define DINO_ATTR(E)                                                                                          \
     if (e == hipSuccess)                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E, KS>),        \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E, KS, KSUB>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DINO_ATTR(EPI_PATCH)
     DINO_ATTR(EPI_QKV)
@@ -332,6 +340,8 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3, 2>();
     if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -458,6 +468,9 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     // pieces, the fragment reads, the MFMAs) is spread over twice the waves: at M = 1 374 FFN-out 32.9 -> 28.3 us (split-K: 27.1),
     // attn-out 12.6 -> 11.2 (10.8), ViT-B attn-out 10.6 -> 9.1.  With more tiles per CU (QKV, FFN-in) co-resident workgroups already
     // overlap each other and the 8-wave tile is slower (17.7 -> 22.5, 20.1 -> 26.2 us): not used there.
+    // (two 64-wide K sub-tiles per LDS stage where K allows: half the wait / barrier links of the serial K loop, 2-6 % at M = 261 ... 1 374)
+    if (!a.small_only && cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st);
     if (!a.small_only && cfg == 2 && t64 < 256)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);
     if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
