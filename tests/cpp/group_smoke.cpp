@@ -1,5 +1,5 @@
 // A C++ caller of the multi-device group API (include/dinov2_hip.h): two ranks on device 0, batch 5 split 3 + 2, logits of
-// the group equal the logits of one session.  Used by tests/test_gpu_group.py::test_group_from_cpp.
+// the group equal the logits of one session, blocking and with two jobs in flight (submit / wait, page-locked buffers).  Used by tests/test_gpu_group.py::test_group_from_cpp.
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -32,7 +32,34 @@ int main(int argc, char** argv) {
     out.logits = ls.data();
     if (dinov2_hip_predict(sess, &in, &out, DINOV2_HIP_CLASSIFY, err, sizeof err) != DINOV2_HIP_OK) return 1;
     dinov2_hip_session_free(sess);
-    const bool same = std::memcmp(lg.data(), ls.data(), lg.size() * sizeof(float)) == 0;
+    // the same batch twice through submit / wait with both jobs in flight (one host thread), images and results in page-locked
+    // buffers from the library's own allocator: the serving loop of INTEGRATION.md section 7
+    bool pipelined = true;
+    {
+        float* pin_in = (float*)dinov2_hip_host_alloc(img.size() * sizeof(float));
+        float* pin_out[2] = {(float*)dinov2_hip_host_alloc(lg.size() * sizeof(float)), (float*)dinov2_hip_host_alloc(lg.size() * sizeof(float))};
+        if (!pin_in || !pin_out[0] || !pin_out[1]) { fprintf(stderr, "host_alloc failed\n"); return 1; }
+        std::memcpy(pin_in, img.data(), img.size() * sizeof(float));
+        dinov2_hip_input pin{pin_in, B, S, S, DINOV2_HIP_RGB_CHW, 0};
+        int64_t t[2];
+        for (int k = 0; k < 2; ++k) {
+            dinov2_hip_output po{};
+            po.logits = pin_out[k];
+            if (dinov2_hip_group_submit(grp, &pin, &po, DINOV2_HIP_CLASSIFY, &t[k], err, sizeof err) != DINOV2_HIP_OK) { fprintf(stderr, "submit: %s\n", err); return 1; }
+        }
+        int64_t extra;
+        dinov2_hip_output po{};
+        po.logits = pin_out[0];
+        pipelined = dinov2_hip_group_submit(grp, &pin, &po, DINOV2_HIP_CLASSIFY, &extra, err, sizeof err) != DINOV2_HIP_OK;  // a third one is refused
+        for (int k = 0; k < 2; ++k) {
+            if (dinov2_hip_group_wait(grp, t[k], err, sizeof err) != DINOV2_HIP_OK) { fprintf(stderr, "wait: %s\n", err); return 1; }
+            pipelined = pipelined && std::memcmp(pin_out[k], ls.data(), ls.size() * sizeof(float)) == 0;
+        }
+        dinov2_hip_host_free(pin_in);
+        dinov2_hip_host_free(pin_out[0]);
+        dinov2_hip_host_free(pin_out[1]);
+    }
+    const bool same = pipelined && std::memcmp(lg.data(), ls.data(), lg.size() * sizeof(float)) == 0;
     printf("group of %d, broadcast %.2f ms, logits %s\n", dinov2_hip_group_size(grp), dinov2_hip_group_broadcast_ms(grp), same ? "equal" : "DIFFER");
     dinov2_hip_group_free(grp);
     if (same) printf("GROUP_OK\n");

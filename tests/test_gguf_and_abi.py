@@ -55,6 +55,35 @@ def test_tensor_data_alignment(pkg, tmp_path):
     assert w.shape == (512, 128) and np.isfinite(w).all() and 0.015 < w.std() < 0.025
 
 
+def test_alignment_rule_is_one_for_loader_and_quantiser(api, pkg, golden_dir, tmp_path):
+    """general.alignment must be a power of two in [1, 2^20] for BOTH native GGUF parsers (the model loader and dinov2_hip_quantize share
+    gguf_alignment_ok): 48 and 2^21 are refused by both with a format error, before any device is touched; 64 loads."""
+    gw = pkg.gguf_writer
+    src = G.GGUFFile(os.path.join(golden_dir, "tiny_gelu_noreg.gguf"))
+    w = gw.GGUFWriter(arch="dinov2", alignment=64)
+    for k, v in src.kv.items():
+        if isinstance(v, (int, np.integer)) and not isinstance(v, bool) and k != "general.alignment":
+            w.add_uint32(k, int(v))
+    w.add_uint32("general.alignment", 64)
+    for name, t in src.tensors.items():
+        w.add_raw_tensor(name, tuple(reversed(t.ne)), t.gtype, t.raw.tobytes())
+    good = str(tmp_path / "align64.gguf")
+    w.write(good)
+    blob = open(good, "rb").read()
+    key = struct.pack("<Q", len("general.alignment")) + b"general.alignment" + struct.pack("<I", 4)
+    at = blob.index(key) + len(key)
+    assert struct.unpack_from("<I", blob, at)[0] == 64
+    err = C.create_string_buffer(256)
+    assert api.lib().dinov2_hip_quantize(good.encode(), str(tmp_path / "ok.gguf").encode(), 8, err, 256) == 0, err.value
+    for bad in (48, 1 << 21):
+        p = tmp_path / f"align{bad}.gguf"
+        p.write_bytes(blob[:at] + struct.pack("<I", bad) + blob[at + 4:])
+        assert api.lib().dinov2_hip_quantize(str(p).encode(), str(tmp_path / "o.gguf").encode(), 8, err, 256) == 2, bad
+        with pytest.raises(api.DinoError) as e:
+            api.Model(str(p))
+        assert e.value.status == 2 and "alignment" in str(e.value), (bad, str(e.value))
+
+
 @pytest.mark.parametrize("tname,bb", [("q4_0", 18), ("q4_1", 20), ("q5_0", 22), ("q5_1", 24), ("q8_0", 34)])
 def test_quant_roundtrip(pkg, tname, bb):
     gw = pkg.gguf_writer
