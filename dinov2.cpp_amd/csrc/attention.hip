@@ -410,7 +410,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 1 : 2) void attention2_kernel(c
     constexpr int KT = 64, ROWB = 128, TILEB = KT * ROWB;
     constexpr bool LSUM = DINO_ATT_LSUM != 0;
     constexpr int QW = 32 * QB, WGQ = NWV * QW;  // queries per wave / per workgroup
-    constexpr int SI = 8 / NWV;                  // 8-row staging pieces per wave, for K and for V
+    constexpr int SI = (8 + NWV - 1) / NWV;      // 8-row staging pieces per wave, for K and for V (three waves: 3, 3, 2)
     // K/V ring depth.  Two slots (the batch-1 kernel): a tile is staged one step before its use, and the other waves of the SIMD
     // cover what is left of its latency.  Three slots (one wave per SIMD: nobody covers anything): a tile is staged TWO steps ahead
     // and the step begins with a counted wait that leaves the newest tile's loads in flight.
@@ -441,21 +441,25 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 1 : 2) void attention2_kernel(c
     // staging offsets as in attention_kernel; K runs one tile ahead of V, so each has its own cursor
     const char* kbase = base + ((size_t)h * 64 + H) * 2;
     const unsigned rowb = (unsigned)H3 * 2u, vdelta = (unsigned)H * 2u;
-    unsigned koff[SI], voff[SI], stmax[SI];
+    unsigned koff[SI], voff[SI], stmax[SI], vswz[SI];
 #pragma unroll
     for (int j = 0; j < SI; ++j) {
         const int r = (j * NWV + wid) * 8 + (lane >> 3);
         const unsigned lc = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         koff[j] = voff[j] = (unsigned)r * rowb + lc;
         stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
+        // V's chunk swizzle against K's (see attention_kernel): depends on the piece's parity and the lane
+        vswz[j] = (unsigned)(((((j * NWV + wid) & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;
     }
-    const unsigned vswz = (unsigned)((((wid & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;  // as in attention_kernel
+    // (with three waves the last wave has no third piece: piece index 8 does not exist)
     auto stage_k1 = [&](int buf, int j) {
+        if (8 % NWV != 0 && j * NWV + wid >= 8) return;
         glds16(kbase + (koff[j] < stmax[j] ? koff[j] : stmax[j]), smem + buf * 2 * TILEB + (j * NWV + wid) * 8 * ROWB);
         koff[j] += KT * rowb;
     };
     auto stage_v1 = [&](int buf, int j) {
-        glds16(kbase + ((voff[j] < stmax[j] ? voff[j] : stmax[j]) ^ vswz) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * NWV + wid) * 8 * ROWB);
+        if (8 % NWV != 0 && j * NWV + wid >= 8) return;
+        glds16(kbase + ((voff[j] < stmax[j] ? voff[j] : stmax[j]) ^ vswz[j]) + vdelta, smem + buf * 2 * TILEB + TILEB + (j * NWV + wid) * 8 * ROWB);
         voff[j] += KT * rowb;
     };
     auto stage_k = [&](int buf) {
@@ -663,6 +667,9 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 1 : 2) void attention2_kernel(c
                     if ((G) == 1) stage_k1(kst, 1);                                                          \
                     if ((G) == 2) stage_v1(vst, 0);                                                          \
                     if ((G) == 3) stage_v1(vst, 1);                                                          \
+                } else if (SI == 3) {                                                                        \
+                    if ((G) < 3) stage_k1(kst, (G));                                                         \
+                    else if ((G) < 6) stage_v1(vst, (G) - 3);                                                \
                 } else {                                                                                     \
                     if ((G) < 4) stage_k1(kst, (G) & (SI - 1));                                              \
                     else stage_v1(vst, ((G) - 4) & (SI - 1));                                                \
@@ -865,10 +872,23 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     const long units = (long)((T + 127) / 128) * nh * B;
     const int ver = forced_ver ? forced_ver : units <= 512 ? 2 : 1;
     if (ver == 2) {
-        const dim3 grid2(((T + 127) / 128) * nh * B), block2(256);
-#define DINO_ATT2(TT, LG) hipLaunchKernelGGL((attention2_kernel<TT, LG>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H)
-        if (dt == DT_F16) { if (log2_scores) DINO_ATT2(_Float16, true); else DINO_ATT2(_Float16, false); }
-        else { if (log2_scores) DINO_ATT2(__bf16, true); else DINO_ATT2(__bf16, false); }
+        // Workgroup size.  Smaller blocks spread a batch-1 forward over more CUs (T = 1 374, 16 heads: 176 workgroups of 128 queries,
+        // 240 of 96, 352 of 64) -- and measure SLOWER there (17.3 / 18.4 / 23.0 us): a wave's serial chain of 22 key tiles is what
+        // the kernel takes, and with fewer waves per workgroup each wave issues more of the tile's staging.  Only short sequences
+        // gain (T = 261: 6.9 -> 6.2 us with 64-query blocks).  DINOV2_HIP_ATTN_NWV=2|3|4 forces a size (testing aid; all sizes give
+        // the same bits).
+        const char* en = getenv("DINOV2_HIP_ATTN_NWV");
+        int nw = en ? atoi(en) : 0;
+        if (nw != 2 && nw != 3 && nw != 4) nw = (T <= 512 && (long)((T + 63) / 64) * nh * B <= 256) ? 2 : 4;
+        const dim3 grid2(((T + 32 * nw - 1) / (32 * nw)) * nh * B), block2(64 * nw);
+#define DINO_ATT2(TT, LG)                                                                                                        \
+        {                                                                                                                        \
+            if (nw == 4) hipLaunchKernelGGL((attention2_kernel<TT, LG, 1, 4>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H); \
+            else if (nw == 3) hipLaunchKernelGGL((attention2_kernel<TT, LG, 1, 3>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H); \
+            else hipLaunchKernelGGL((attention2_kernel<TT, LG, 1, 2>), grid2, block2, 0, st, (const TT*)qkv, (TT*)out, T, H); \
+        }
+        if (dt == DT_F16) { if (log2_scores) DINO_ATT2(_Float16, true) else DINO_ATT2(_Float16, false) }
+        else { if (log2_scores) DINO_ATT2(__bf16, true) else DINO_ATT2(__bf16, false) }
 #undef DINO_ATT2
         return hipGetLastError();
     }

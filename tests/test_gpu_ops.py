@@ -205,6 +205,13 @@ def test_attention_kernels_agree_bit_for_bit(api, monkeypatch, T):
     assert np.array_equal(outs["1"], outs["2"])
     assert np.array_equal(outs["1"], outs["3"])
     assert np.array_equal(outs["1"], outs["4"])
+    # the pipelined kernel's smaller workgroups (64- and 96-query blocks: what a batch-1 forward picks to fill the chip)
+    monkeypatch.setenv("DINOV2_HIP_ATTN_V", "2")
+    for nwv in ("2", "3", "4"):
+        monkeypatch.setenv("DINOV2_HIP_ATTN_NWV", nwv)
+        out = np.zeros((B * T, H), np.float32)
+        assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
+        assert np.array_equal(outs["1"], out), nwv
 
 
 def test_attention_online_softmax_rescale(api):
