@@ -64,7 +64,10 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     // logical tile id -> (m0, n0): groups of GM row panels are swept column by column, so the 32 tiles an XCD runs side
     // by side form an 8 x 4 patch (8 activation panels + 4 weight panels live in its L2) instead of 2 x 16
     // (2 + 16 panels): ~1.5x less refill traffic per K step.  Pure speed choice.
-    constexpr int GM = 8;
+#ifndef DINO_GEMM_GM
+#define DINO_GEMM_GM 8  // (tuning builds: -DDINO_GEMM_GM=4|16|32; traffic and time of each in profiles/r03_gemm_notes.md section 4)
+#endif
+    constexpr int GM = DINO_GEMM_GM;
     auto tile_mn = [&](int lid, int& m0, int& n0) {
         const int g = lid / (GM * ntn), r = lid - g * (GM * ntn);
         const int gm = ntm - g * GM < GM ? ntm - g * GM : GM;
