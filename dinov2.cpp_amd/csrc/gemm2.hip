@@ -17,6 +17,8 @@
 //     second LDS buffer and moves whole 128-byte lines (lane l owns 16 B of row 8*it + (l >> 3)); residual-stream reads are
 //     issued one pass ahead of the stores that would otherwise force a vmcnt(0) drain (gfx950 counts stores on vmcnt).
 // LDS swizzle and the XCD-aware tile order are those of gemm.hip.
+#include <cstdio>
+
 #include "device_types.h"
 #include "kernels.h"
 
@@ -25,6 +27,19 @@
 // profiles/r02_gemm_kloop.md.  The product kernel has one schedule.
 
 namespace dinov2 {
+
+// -DDINO_GEMM_PROF (tuning builds): s_memtime sums per workgroup -- [0] tile prologue (both barriers + the counted wait), [1] K loop,
+// [2] epilogue, [3] tiles -- of wave 0 and of wave 4 (+ 4), printed by the launcher after each launch.
+#ifdef DINO_GEMM_PROF
+__device__ unsigned long long g_gemm_prof[256 * 8];
+#define DINO_GP_INIT unsigned long long gp_t = __builtin_readcyclecounter(), gp_acc[4] = {0, 0, 0, 0};
+#define DINO_GP(i) { const unsigned long long t__ = __builtin_readcyclecounter(); gp_acc[i] += t__ - gp_t; gp_t = t__; }
+#define DINO_GP_FLUSH if (lane == 0 && (wid == 0 || wid == 4)) for (int i__ = 0; i__ < 4; ++i__) g_gemm_prof[blockIdx.x * 8 + (wid ? 4 : 0) + i__] += gp_acc[i__];
+#else
+#define DINO_GP_INIT
+#define DINO_GP(i)
+#define DINO_GP_FLUSH
+#endif
 
 // XREP = 32-token blocks per wave along M: 4 -> 256-row tiles (the main configuration), 3 -> 192-row tiles, used by the
 // dispatcher for the LAST partial round of a launch (688 tiles of 256 rows on 256 CUs are 2.69 rounds -> 3; two rounds of
@@ -134,9 +149,11 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         stage(1, 0, 0);
         stage(3, 0, 0);
     }
+    DINO_GP_INIT
     for (int tix = bidx; tix < chunkn; tix += nb_x) {
         int m0, n0;
         tile_mn(chunk0 + tix, m0, n0);
+        DINO_GP(2)  // (time since the end of the previous tile's stamps: none)
         const bool has_next = tix + nb_x < chunkn;
 
         // acc[a][b][i][j][e] = C[m0 + wx * 32 XREP + 64 a + 16 i + (lane & 15)][n0 + ww * 64 + 32 b + 16 j + 4 (lane >> 4) + e]
@@ -221,6 +238,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but those four: K-tile 0 has landed (and the previous tile's stores)
         DINO_BAR()
         if (wx == 1) DINO_BAR()  // wave-row 1 runs one barrier behind wave-row 0
+        DINO_GP(0)
 
         for (int t = 0; t < nk; ++t) {
             const unsigned bo = (unsigned)(t & 1) * (unsigned)BUF;
@@ -258,6 +276,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             DINO_PHASE_END(1, 0)
         }
         if (wx == 0) DINO_BAR()
+        DINO_GP(1)
 #undef DINO_DSR
 #undef DINO_READ_X
 #undef DINO_READ_W
@@ -441,7 +460,12 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        DINO_GP(2)
+#ifdef DINO_GEMM_PROF
+        gp_acc[3] += 1;
+#endif
     }  // persistent tile loop
+    DINO_GP_FLUSH
 }
 
 template <typename T, int EPI, int XREP>
@@ -460,6 +484,21 @@ __global__ __launch_bounds__(512) void gemm2_mixed_kernel(GemmArgs p, GemmArgs q
     gemm2_body<T, EPI, 4>(p, smem);
     gemm2_body<T, EPI, 3>(q, smem);
 }
+
+#ifdef DINO_GEMM_PROF
+static void gemm_prof_dump(const char* what, int nblocks) {
+    static unsigned long long h[256 * 8], z[256 * 8];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm_prof), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof z);
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        for (int i = 0; i < 8; ++i) a[i] += (double)h[b * 8 + i];
+    const double t0 = a[3] > 0 ? a[3] : 1, t4 = a[7] > 0 ? a[7] : 1;
+    fprintf(stderr, "gemm_prof %s: cycles per tile, wave 0: prologue %.0f  K loop %.0f  epilogue %.0f (%.1f tiles/block) | wave 4: %.0f %.0f %.0f\n", what,
+            a[0] / t0, a[1] / t0, a[2] / t0, a[3] / nblocks, a[4] / t4, a[5] / t4, a[6] / t4);
+}
+#endif
 
 template <typename T, int XREP>
 static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
@@ -482,6 +521,9 @@ static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         DINO_L2(EPI_PLAIN_F32)
     }
 #undef DINO_L2
+#ifdef DINO_GEMM_PROF
+    gemm_prof_dump(epi == EPI_QKV ? "plain-launch QKV" : "plain-launch", (int)grid.x);
+#endif
     return hipGetLastError();
 }
 
@@ -489,6 +531,7 @@ static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
 hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     return dt == DT_F16 ? launch2_t<_Float16, 4>(epi, a, st) : launch2_t<__bf16, 4>(epi, a, st);
 }
+
 
 template <typename T>
 static hipError_t launch2_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
@@ -507,6 +550,9 @@ static hipError_t launch2_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArg
         default: return hipErrorInvalidValue;
     }
 #undef DINO_LM
+#ifdef DINO_GEMM_PROF
+    gemm_prof_dump(epi == EPI_GELU ? "mixed GELU" : epi == EPI_RESID ? "mixed RESID" : epi == EPI_QKV ? "mixed QKV" : "mixed", 256);
+#endif
     return hipGetLastError();
 }
 
