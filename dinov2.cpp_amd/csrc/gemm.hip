@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                     if (row < M && c2 < N) {
                         const float h1 = acc[i][jh][r] + b1, h2 = acc[i][jh + 2][r] + b2;
                         float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1)) * h2;  // silu(x1) * x2, dinov2.cpp:605
-                        asm volatile("" : "+v"(sl));
+                        asm("" : "+v"(sl));
                         out[(size_t)row * p.ldo + hu] = E::from_f32(sl);
                     }
                 }
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = acc[i][jn][r] + bias[r];
-                    asm volatile("" : "+v"(v[r]));  // f32 value first, then any f16 rounding (no v_fma_mix fusion: gemm2.hip)
+                    asm("" : "+v"(v[r]));  // f32 value first, then any f16 rounding (no v_fma_mix fusion: gemm2.hip)
                 }
                 if constexpr (EPI == EPI_PATCH) {
                     const int b = row / p.P, pp = row - b * p.P;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                     for (int r = 0; r < 4; ++r) {
                         if constexpr (EPI == EPI_QKV) {
                             float vq = v[r] * auxv[r];
-                            asm volatile("" : "+v"(vq));
+                            asm("" : "+v"(vq));
                             o[r] = E::from_f32(vq);
                         } else {
                             // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))).  EXACTLY the expression of
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                             const float xr = (float)(_Float16)v[r];
                             const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
                             float g = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-                            asm volatile("" : "+v"(g));
+                            asm("" : "+v"(g));
                             o[r] = E::from_f32((float)(_Float16)g);
                         }
                     }

@@ -310,8 +310,20 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             // fall inside a 256-column tile
             const float qs = (EPI == EPI_QKV && n0 + ww * 64 < p.qcols) ? p.qscale : 1.0f;
             constexpr int BN_ = EPI == EPI_SWIGLU ? 1 : 2;
+            // SUBP sub-passes per token half.  1: 64 rows through the wave's whole 8 KiB slice.  2 (the epilogues with real VALU work
+            // per element): 32 rows through alternating 4 KiB halves of the slice, so that the stores of one sub-pass and the
+            // arithmetic of the next are independent and the two waves of a SIMD -- which share its VALU -- fall out of step.
+#ifdef DINO_EPI_SPLIT
+            constexpr int SUBP = EPI == EPI_SWIGLU ? 1 : 2;
+#else
+            constexpr int SUBP = 1;
+#endif
+            constexpr int IPS = 4 / SUBP;  // 16-row blocks per sub-pass
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
+            for (int sp = 0; sp < 2 * SUBP; ++sp) {
+                const int q = sp / SUBP, ih = sp % SUBP;
+                if (q == 1 && ih * IPS >= NI1) continue;  // 192-row tiles: the second token half has 32 rows
+                char* const eh = ep + (SUBP == 2 ? (sp & 1) * 4096 : 0);
 #pragma unroll
                 for (int b = 0; b < BN_; ++b)
 #pragma unroll
@@ -319,7 +331,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                         const float bb[4] = {bs[b][j].x, bs[b][j].y, bs[b][j].z, bs[b][j].w};
                         const float b2[4] = {bs[1][j].x, bs[1][j].y, bs[1][j].z, bs[1][j].w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
+                        for (int i = ih * IPS; i < (ih + 1) * IPS; ++i) {
                             if (q == 1 && i >= NI1) continue;  // 192-row tiles: the second pass has 32 rows
                             vec4 o;
 #ifndef DINO_GELU_SCALAR
@@ -332,13 +344,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                                 for (int e2 = 0; e2 < 2; ++e2) {
                                     f32x2 v = {acc[q][b][i][j][2 * e2], acc[q][b][i][j][2 * e2 + 1]};
                                     v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
-                                    asm volatile("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
+                                    asm("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
                                     const f32x2 xr = {(float)(_Float16)v[0], (float)(_Float16)v[1]};
                                     const f32x2 c1 = {-0.1029432397f, -0.1029432397f}, c2 = {-2.302208199f, -2.302208199f};
                                     const f32x2 t = xr * __builtin_elementwise_fma(xr * xr, c1, c2);  // -2 log2(e) u
                                     const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                                     f32x2 gl = xr * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
-                                    asm volatile("" : "+v"(gl));
+                                    asm("" : "+v"(gl));
                                     o[2 * e2] = E::from_f32((float)(_Float16)gl[0]);
                                     o[2 * e2 + 1] = E::from_f32((float)(_Float16)gl[1]);
                                 }
@@ -351,16 +363,16 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                                 // into v_fma_mixlo_f16 for SOME unrolled instances (single rounding instead of the
                                 // reference's f32-then-f16 double rounding), which made results depend on the row's
                                 // position in the tile
-                                asm volatile("" : "+v"(v));
+                                asm("" : "+v"(v));
                                 if constexpr (EPI == EPI_QKV) {
                                     float vq = v * qs;
-                                    asm volatile("" : "+v"(vq));
+                                    asm("" : "+v"(vq));
                                     o[e] = E::from_f32(vq);
                                 } else if constexpr (EPI == EPI_SWIGLU) {
                                     // W rows interleaved in 32-blocks: column half 0 holds x1[32 units], half 1 holds x2 of the same units
                                     const float h2 = acc[q][1][i][j][e] + b2[e];
                                     float sg = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2;  // silu(x1) * x2
-                                    asm volatile("" : "+v"(sg));
+                                    asm("" : "+v"(sg));
                                     o[e] = E::from_f32(sg);
                                 } else {
                                     // EPI_GELU, ggml semantics: y = table[f16(x)], table[h] = f16(gelu_tanh(f32(h))).
@@ -370,13 +382,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                                     const float xr = (float)(_Float16)v;
                                     const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
                                     float gl = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
-                                    asm volatile("" : "+v"(gl));
+                                    asm("" : "+v"(gl));
                                     o[e] = E::from_f32((float)(_Float16)gl);
                                 }
                             }
-                            const int row = i * 16 + er;
+                            const int row = (i - ih * IPS) * 16 + er;  // row within the sub-pass
                             const int slot = (4 * b + 2 * j + (eq >> 1)) ^ (row & 7);  // 8 columns (16 B) per slot
-                            *(vec4*)(ep + row * 128 + slot * 16 + (eq & 1) * 8) = o;
+                            *(vec4*)(eh + row * 128 + slot * 16 + (eq & 1) * 8) = o;
                         }
                     }
                 __builtin_amdgcn_wave_barrier();
@@ -385,22 +397,25 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int row = it * 16 + (el >> 2), slot = el & 3;
-                        const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                        const u32x4 v = *(const u32x4*)(eh + row * 128 + ((slot ^ (row & 7)) << 4));
                         const int m = mbase + q * 64 + row;
                         if (m < M && (XREP == 4 || q * 64 + row < 32 * XREP))
                             *(u32x4*)((T*)p.out + (size_t)m * p.ldo + hid0 + slot * 8) = v;
                     }
                 } else {
 #pragma unroll
-                    for (int it = 0; it < 8; ++it) {
+                    for (int it = 0; it < 8 / SUBP; ++it) {
                         const int row = it * 8 + (el >> 3), slot = el & 7;
-                        const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
-                        const int m = mbase + q * 64 + row;
-                        if (m < M && (XREP == 4 || q * 64 + row < 32 * XREP))
+                        const u32x4 v = *(const u32x4*)(eh + row * 128 + ((slot ^ (row & 7)) << 4));
+                        const int tr = q * 64 + ih * (64 / SUBP) + row;  // token row within the wave's 128
+                        const int m = mbase + tr;
+                        if (m < M && (XREP == 4 || tr < 32 * XREP))
                             *(u32x4*)((T*)p.out + (size_t)m * p.ldo + n0 + ww * 64 + slot * 8) = v;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                // (two halves: the next sub-pass writes the OTHER half, and a wave's LDS operations execute in order, so only the
+                //  write -> read fence above is needed)
+                if (SUBP == 1) __builtin_amdgcn_wave_barrier();
             }
         } else {
             // 4-byte outputs: four passes of 64 rows x 32 columns (128 B per row).  All loads of a pass (residual stream /
