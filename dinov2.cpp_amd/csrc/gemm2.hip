@@ -345,7 +345,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
                                     f32x2 v = {acc[q][b][i][j][2 * e2], acc[q][b][i][j][2 * e2 + 1]};
                                     v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
                                     asm("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
-                                    const f32x2 xr = {(float)(_Float16)v[0], (float)(_Float16)v[1]};
+                                    // (vector converts: one v_cvt_pk_f16_f32 + v_cvt_f32_f16 / its SDWA form instead of four scalar converts)
+                                    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                                    const f32x2 xr = __builtin_convertvector(__builtin_convertvector(v, f16x2), f32x2);
                                     const f32x2 c1 = {-0.1029432397f, -0.1029432397f}, c2 = {-2.302208199f, -2.302208199f};
                                     const f32x2 t = xr * __builtin_elementwise_fma(xr * xr, c1, c2);  // -2 log2(e) u
                                     const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
