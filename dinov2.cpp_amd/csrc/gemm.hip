@@ -56,6 +56,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     const size_t lda = p.lda ? p.lda : K, ldw = p.ldw ? p.ldw : K;
 
     const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
+    const size_t kslice = blockIdx.y;  // K slice of a cross-workgroup split (GemmArgs.kslices; 0 otherwise)
     const int lid = xcd_remap(blockIdx.x, ntn * ntm);
     const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
 
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        asrc[j] = (const char*)p.A + ((size_t)gm * lda) * 2 + lc * 16;
+        asrc[j] = (const char*)p.A + ((size_t)gm * lda + kslice * (size_t)K) * 2 + lc * 16;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row;
         gn = gn < N ? gn : N - 1;
-        bsrc[j] = (const char*)p.W + ((size_t)gn * ldw) * 2 + lc * 16;
+        bsrc[j] = (const char*)p.W + ((size_t)gn * ldw + kslice * (size_t)K) * 2 + lc * 16;
     }
 
     char* const smem = smem_all + grp * (NST * STAGE);  // this group's LDS ring
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                             if (col0 + r < N) x[col0 + r] = v[r] * auxv[r] + x[col0 + r];
                     }
                 } else if constexpr (EPI == EPI_PLAIN_F32) {
-                    float* x = (float*)p.out + (size_t)row * p.ldo;
+                    float* x = (float*)p.out + kslice * p.kslice_ostride + (size_t)row * p.ldo;
                     if (full) *(float4*)(x + col0) = make_float4(v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1, int KSUB = 1>
 static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-    const dim3 grid(ntn * ntm), block(WM * WN * 64 * KS);
+    const dim3 grid(ntn * ntm, a.kslices > 1 ? a.kslices : 1), block(WM * WN * 64 * KS);
     const size_t lds = KS * NST * KSUB * (size_t)(BM + BN) * 128;
 #define DINO_LAUNCH(E)                                                                             \
     case E:                                                                                        \
@@ -366,6 +367,10 @@ hipError_t gemm_init() {
 // 221 -> 244 images/s.  DINOV2_HIP_GEMM_TILE=128|256 forces E / A (testing aid: include/dinov2_hip.h, "Environment").
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    if (a.kslices > 1) {  // cross-workgroup K split (tiny M, low-latency mode): the 8-wave small tile on every slice
+        if (epi != EPI_PLAIN_F32 || a.bias || (a.K / 64) % 2 != 0 || !a.lda || !a.ldw) return hipErrorInvalidValue;
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st);
+    }
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
     // rows are fetched with 16-byte global -> LDS DMA pieces and 16-byte vector loads: strides must keep rows 16-byte aligned

@@ -61,6 +61,7 @@ struct dinov2_hip_session {
     float *img = nullptr, *x = nullptr, *fin = nullptr, *feat = nullptr, *logits = nullptr, *probs = nullptr,
           *pos = nullptr;
     void *col = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    float* part = nullptr;  // K-slice partial products of the FFN-out GEMM (tiny M, low-latency mode only; else null)
     int pos_h = -1, pos_w = -1;  // grid the cached interpolated pos-embed in `pos` belongs to
     std::vector<float> pos_stage;
     // hipGraph cache (the "allocr reuse" of the reference taken one step further): a forward that repeats with the same

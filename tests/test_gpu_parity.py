@@ -260,6 +260,36 @@ def test_image_result_independent_of_batch_size(api, pkg, tmp_path):
     assert np.abs(one["patch_tokens"][0] - full["patch_tokens"][23]).max() <= 5e-3 * max(1.0, np.abs(full["patch_tokens"][23]).max())
 
 
+@pytest.mark.parametrize("model,layers", [("large", 3), ("small", 4), ("base", 2)])
+def test_low_latency_mode_k_sliced_ffn_out_tiny_batches(api, pkg, tmp_path, model, layers):
+    """Opt-in low-latency mode (batch_invariant = 0) at the reference's own regime, 224 x 224, batch 1 (T = 257 + 4): the FFN-out
+    GEMM is cut along K ACROSS workgroups (4 x 1 024 for ViT-L, 3 x 1 024 for ViT-B, 3 x 512 for ViT-S) and bias + LayerScale +
+    residual move into the LayerNorm launch that follows (norm1 of the next layer / the final LayerNorm).  Against the default
+    (batch-invariant) mode and the oracle to the stated bound; bit-reproducible run to run; debug_hidden (which stops before a
+    LayerNorm) sees the completed residual stream; batch 2 -- still M <= 512 only for T = 261 -- takes the same path."""
+    path = str(tmp_path / f"{model}{layers}.gguf")
+    pkg.synth.write_synthetic_gguf(path, model, registers=4, num_classes=1000, seed=13, layers=layers)
+    imgs = pkg.synth.synthetic_images(2, 224, 224, seed=13)
+    ref = api.Session(api.Model(path, classify=True))
+    fast = api.Session(api.Model(path, classify=True, batch_invariant=False))
+    exp = OracleModel(path).forward(imgs[0], classify=True)
+    for B in (1, 2):
+        a = ref.predict(imgs[:B], classify=True)
+        b = fast.predict(imgs[:B], classify=True)
+        again = fast.predict(imgs[:B], classify=True)
+        assert np.array_equal(b["logits"], again["logits"]) and np.array_equal(b["patch_tokens"], again["patch_tokens"])
+        assert not np.array_equal(a["patch_tokens"], b["patch_tokens"])  # the sliced plan really ran
+        assert _rel(b["logits"], a["logits"]) <= 1e-3 and _rel(b["patch_tokens"], a["patch_tokens"]) <= 5e-3
+        assert _rel(b["logits"][0], exp["logits"]) <= 1e-3 and _rel(b["patch_tokens"][0], exp["patch_tokens"]) <= 5e-3
+    feats = fast.predict(imgs[:1], classify=False)  # features: the final LayerNorm is the one that completes the last layer
+    assert _rel(feats["patch_tokens"], ref.predict(imgs[:1], classify=False)["patch_tokens"]) <= 5e-3
+    for layer in (1, layers):
+        ha, hb = ref.debug_hidden(imgs[:1], layer), fast.debug_hidden(imgs[:1], layer)
+        assert np.abs(ha - hb).max() <= 2e-3 * max(1.0, np.abs(ha).max()), layer
+    big = pkg.synth.synthetic_images(3, 224, 224, seed=14)  # M = 783 > 512: back to the in-workgroup split of the two N = hidden GEMMs
+    assert _rel(fast.predict(big, classify=True)["logits"], ref.predict(big, classify=True)["logits"]) <= 1e-3
+
+
 @pytest.mark.parametrize("dtype_name,scale", [("f16", 1.0), ("bf16", 8.0)])
 def test_full_size_giant_swiglu(api, pkg, tmp_path, dtype_name, scale):
     """BASELINE config 4 shapes (ViT-g/14: H = 1536, 24 heads, SwiGLU 8192 -> 4096; 2 of its 40 layers to keep the oracle
