@@ -286,6 +286,15 @@ def test_low_latency_mode_k_sliced_ffn_out_tiny_batches(api, pkg, tmp_path, mode
     for layer in (1, layers):
         ha, hb = ref.debug_hidden(imgs[:1], layer), fast.debug_hidden(imgs[:1], layer)
         assert np.abs(ha - hb).max() <= 2e-3 * max(1.0, np.abs(ha).max()), layer
+    # bf16 compute takes the same path (8 x the f16 bounds, as everywhere for bf16 on shallow models); 50 repeats as a race screen
+    rb = api.Session(api.Model(path, classify=True, dtype=api.BF16))
+    fb = api.Session(api.Model(path, classify=True, dtype=api.BF16, batch_invariant=False))
+    a, b = rb.predict(imgs[:1], classify=True), fb.predict(imgs[:1], classify=True)
+    assert _rel(b["logits"], a["logits"]) <= 8e-3 and _rel(b["patch_tokens"], a["patch_tokens"]) <= 4e-2
+    first = fast.predict(imgs[:2], classify=True)
+    for _ in range(50):
+        again = fast.predict(imgs[:2], classify=True)
+        assert np.array_equal(first["logits"], again["logits"]) and np.array_equal(first["patch_tokens"], again["patch_tokens"])
     big = pkg.synth.synthetic_images(3, 224, 224, seed=14)  # M = 783 > 512: back to the in-workgroup split of the two N = hidden GEMMs
     assert _rel(fast.predict(big, classify=True)["logits"], ref.predict(big, classify=True)["logits"]) <= 1e-3
 
