@@ -474,9 +474,9 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     // attn-out 12.6 -> 11.2 (10.8), ViT-B attn-out 10.6 -> 9.1.  With more tiles per CU (QKV, FFN-in) co-resident workgroups already
     // overlap each other and the 8-wave tile is slower (17.7 -> 22.5, 20.1 -> 26.2 us): not used there.
     // (two 64-wide K sub-tiles per LDS stage where K allows: half the wait / barrier links of the serial K loop, 2-6 % at M = 261 ... 1 374)
-    if (!a.small_only && cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)
+    if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st);
-    if (!a.small_only && cfg == 2 && t64 < 256)
+    if (cfg == 2 && t64 < 256)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);
     if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
     if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
