@@ -30,6 +30,21 @@ namespace dinov2 {
 // kernel, so it is used only when the caller allows it (GemmArgs.allow_ksplit; dinov2_hip_load_opts.batch_invariant = 0).
 // KSUB = 64-wide K sub-tiles per LDS stage (1, or 2 for the few-tile shapes of a small batch: their K loop is a serial chain of
 // wait -> barrier -> issue -> read -> MFMA per stage, and a stage twice as deep halves the number of links; same K order).
+// -DDINO_GEMM_SPROF (tuning builds): wall-clock (100 MHz) sums of wave 0 of every workgroup -- [0] set-up and the first stages' issue, [1] counted
+// wait + barrier, [2] issuing the next stage, [3] fragment reads + MFMAs, [4] epilogue, [5] workgroups -- printed after each launch.
+#ifdef DINO_GEMM_SPROF
+__device__ unsigned long long g_sprof[8];
+__device__ unsigned long long g_sprof_t[2 * 1024];  // wall clock (100 MHz) at entry / exit of each workgroup
+#define DINO_SP_INIT const unsigned long long sp_w0 = wall_clock64(); unsigned long long sp_t = sp_w0, sp_acc[5] = {0, 0, 0, 0, 0};
+#define DINO_SP(i) { const unsigned long long t__ = wall_clock64(); sp_acc[i] += t__ - sp_t; sp_t = t__; }
+#define DINO_SP_FLUSH if (tid == 0) { for (int i__ = 0; i__ < 5; ++i__) atomicAdd(&g_sprof[i__], sp_acc[i__]); atomicAdd(&g_sprof[5], 1ull); \
+        if (blockIdx.x < 1024 && blockIdx.y == 0) { g_sprof_t[2 * blockIdx.x] = sp_w0; g_sprof_t[2 * blockIdx.x + 1] = wall_clock64(); } }
+#else
+#define DINO_SP_INIT
+#define DINO_SP(i)
+#define DINO_SP_FLUSH
+#endif
+
 template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI, int KS = 1, int KSUB = 1>
 __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma clang fp contract(off)  // position-independent results: see gemm2.hip
@@ -43,9 +58,10 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int MREP = WTM / 16, NREP = WTN / 16;  // 16 x 16 accumulator blocks of the wave tile (MFMA 16x16x32)
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // glds wave-instructions per wave per tile
-    static_assert(NREP == 4, "SwiGLU pairing and the register budget assume a 64-wide wave tile");
+    static_assert(NREP == 4 || EPI != EPI_SWIGLU, "the SwiGLU pairing assumes a 64-wide wave tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    DINO_SP_INIT
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,6 +126,31 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- epilogue operands, fetched BEFORE the K loop: these kernels live for 10-30 us, and a bias / LayerScale / residual fetch issued
+    // after the last MFMA costs a whole memory round trip (2-4 k cycles of a 20-60 k cycle workgroup) that the K loop can hide.
+    // vec_ok (uniform): every column of the tile exists and all row starts are 16-byte aligned -> vector loads and stores, no column guards.
+    // acc[i][j][r] is C[row, col]: row = m0 + wm*WTM + i*16 + (lane&15), col = n0 + wn*WTN + j*16 + 4*(lane>>4) + r.
+    const int colb = n0 + wn * WTN + 4 * fh;
+    const int rowb = m0 + wm * WTM + fr;
+    const bool vec_ok = EPI != EPI_SWIGLU && EPI != EPI_PATCH && n0 + BN <= N && (p.ldo & 3) == 0 && (p.qcols & 3) == 0 &&
+                        (((size_t)p.bias | (size_t)p.aux) & 15) == 0;
+    f32x4 bias4[NREP], aux4[NREP], xin4[EPI == EPI_RESID ? MREP : 1][NREP];
+    if (vec_ok) {
+#pragma unroll
+        for (int jn = 0; jn < NREP; ++jn) {
+            const int col0 = colb + jn * 16;
+            bias4[jn] = p.bias ? *(const f32x4*)(p.bias + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_RESID) {
+                aux4[jn] = *(const f32x4*)(p.aux + col0);
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) {
+                    const int row = rowb + i * 16 < M ? rowb + i * 16 : M - 1;  // (clamped: rows past M are never stored)
+                    xin4[i][jn] = *(const f32x4*)((const float*)p.out + (size_t)row * p.ldo + col0);
+                }
+            }
+        }
+    }
+
     // NST-stage LDS ring, tiles kt+1 .. kt+NST-1 in flight while tile kt is multiplied: with few workgroups per CU (small M)
     // nothing else hides the global -> LDS latency.  One barrier per K tile: (a) every wave's loads of tile kt have landed
     // (each wave waits for its own with a counted vmcnt -- loads return in order -- before the barrier), (b) every wave is
@@ -121,14 +162,18 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
     int buf = 0, nbuf = NST - 1;
+    DINO_SP(0)
     for (int kt = 0; kt < nk; ++kt) {
         const int ahead = nk - 1 - kt < NST - 2 ? nk - 1 - kt : NST - 2;  // younger tiles that may still be in flight
         if (NST == 2 || ahead == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(LPT) : "memory");
         else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * LPT < 64 ? 2 * LPT : 0) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPT < 64 ? 3 * LPT : 0) : "memory");
-        static_assert(NST <= 5, "extend the vmcnt dispatch above");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(3 * LPT < 64 ? 3 * LPT : 0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(4 * LPT < 64 ? 4 * LPT : 0) : "memory");
+        static_assert(NST <= 6, "extend the vmcnt dispatch above");
+        DINO_SP(1)
         if (kt + NST - 1 < nk) stage(nbuf, kt + NST - 1);
+        DINO_SP(2)
         const char* s0 = smem + buf * STAGE;
         nbuf = buf;  // the buffer just consumed is the next to be refilled
         buf = buf + 1 == NST ? 0 : buf + 1;
@@ -149,6 +194,10 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                     acc[i][j] = E::mfma16(bf[j], af[i], acc[i][j]);  // operand swap (as gemm2.hip): a lane owns one row, four columns
                 }
         }
+#ifdef DINO_GEMM_SPROF
+        asm volatile("s_nop 0" : "+v"(acc[0][0]));  // the section ends when the last MFMA chain's first link has issued, not retired
+#endif
+        DINO_SP(3)
     }
 
     if constexpr (KS == 2) {
@@ -178,9 +227,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     // ---- epilogue: acc[i][j][r] is C[row, col] with
     //      row = m0 + wm*WTM + i*16 + (lane&15),  col = n0 + wn*WTN + j*16 + 4*(lane>>4) + r   (r = 0..3: four consecutive columns)
     // Edge-guarded per element in M and N (N = 1000-style shapes take the scalar path for their last columns).
-    const int colb = n0 + wn * WTN + 4 * fh;
-    const int rowb = m0 + wm * WTM + fr;
-
     if constexpr (EPI == EPI_SWIGLU) {
         // W rows interleaved in 32-blocks: columns 0..31 of the wave's 64 hold x1[32 units], columns 32..63 x2 of the same units
         T* out = (T*)p.out;
@@ -204,6 +250,72 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                 }
             }
         return;
+    } else if (vec_ok) {
+        // the common case: whole tile inside N, aligned rows; the operands were fetched before the K loop.  Arithmetic identical, expression
+        // by expression, to the guarded path below (and to gemm2.hip).
+        // One unconditional use of every prefetched register first: the compiler then waits for those loads HERE, once.  Left to the
+        // row-guarded blocks below it puts an `s_waitcnt vmcnt(0)` into each of them, and on gfx9 vmcnt also counts stores: every
+        // block would wait for the previous block's store to retire (measured: 8.8 us of a 20 us FFN-in launch at M = 1 374).
+#pragma unroll
+        for (int jn = 0; jn < NREP; ++jn) {
+            asm volatile("" ::"v"(bias4[jn]));
+            if constexpr (EPI == EPI_RESID) {
+                asm volatile("" ::"v"(aux4[jn]));
+#pragma unroll
+                for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(xin4[i][jn]));
+            }
+        }
+#pragma unroll
+        for (int jn = 0; jn < NREP; ++jn) {
+            const int col0 = colb + jn * 16;
+#pragma unroll
+            for (int i = 0; i < MREP; ++i) {
+                const int row = rowb + i * 16;
+                if (row >= M) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[i][jn][r] + bias4[jn][r];
+                    asm("" : "+v"(v[r]));
+                }
+                if constexpr (EPI == EPI_RESID) {
+                    float* x = (float*)p.out + (size_t)row * p.ldo + col0;
+                    const f32x4 xi = xin4[i][jn], au = aux4[jn];
+                    *(f32x4*)x = f32x4{v[0] * au[0] + xi[0], v[1] * au[1] + xi[1], v[2] * au[2] + xi[2], v[3] * au[3] + xi[3]};
+                } else if constexpr (EPI == EPI_PLAIN_F32) {
+                    float* x = (float*)p.out + kslice * p.kslice_ostride + (size_t)row * p.ldo + col0;
+                    *(f32x4*)x = f32x4{v[0], v[1], v[2], v[3]};
+                } else {
+                    typename E::vec4 o;
+                    if constexpr (EPI == EPI_QKV) {
+                        const float qs = col0 < p.qcols ? p.qscale : 1.0f;  // (qcols % 4 == 0: one answer for the lane's four columns)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float vq = v[r] * qs;
+                            asm("" : "+v"(vq));
+                            o[r] = E::from_f32(vq);
+                        }
+                    } else {
+                        // two columns per instruction (v_pk_*_f32; v_exp / v_rcp / the conversions per element), exactly as gemm2.hip
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int e2 = 0; e2 < 2; ++e2) {
+                            const f32x2 vv = {v[2 * e2], v[2 * e2 + 1]};
+                            const f32x2 xr = __builtin_convertvector(__builtin_convertvector(vv, f16x2), f32x2);
+                            const f32x2 c1 = {-0.1029432397f, -0.1029432397f}, c2 = {-2.302208199f, -2.302208199f};
+                            const f32x2 t = xr * __builtin_elementwise_fma(xr * xr, c1, c2);  // -2 log2(e) u
+                            const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                            f32x2 gl = xr * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                            asm("" : "+v"(gl));
+                            o[2 * e2] = E::from_f32((float)(_Float16)gl[0]);
+                            o[2 * e2 + 1] = E::from_f32((float)(_Float16)gl[1]);
+                        }
+                    }
+                    *(typename E::vec4*)((T*)p.out + (size_t)row * p.ldo + col0) = o;
+                }
+            }
+        }
     } else {
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
@@ -284,6 +396,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
             }
         }
     }
+    DINO_SP(4)
+    DINO_SP_FLUSH
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1, int KSUB = 1>
@@ -300,10 +414,42 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         DINO_LAUNCH(EPI_QKV)
         DINO_LAUNCH(EPI_RESID)
         DINO_LAUNCH(EPI_GELU)
-        DINO_LAUNCH(EPI_SWIGLU)
         DINO_LAUNCH(EPI_PLAIN_F32)
+        case EPI_SWIGLU:  // (its column pairing needs 64-wide wave tiles)
+            if constexpr (BN / WN == 64) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, EPI_SWIGLU, KS, KSUB>), grid, block, lds, st, a);
+            else return hipErrorInvalidValue;
+            break;
     }
 #undef DINO_LAUNCH
+#ifdef DINO_GEMM_SPROF
+    {
+        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sprof), sizeof h);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sprof), z, sizeof z);
+        const double n = h[5] ? (double)h[5] : 1.0;
+        static int shown = 0;
+        if (shown++ % 50 == 49) {  // (every 50th launch: the bench loops)
+            static unsigned long long tt[2 * 1024];
+            (void)hipMemcpyFromSymbol(tt, HIP_SYMBOL(g_sprof_t), sizeof tt);
+            const int nb = (int)grid.x < 1024 ? (int)grid.x : 1024;
+            unsigned long long t0 = ~0ull, t1 = 0, slast = 0;
+            double life = 0, lmax = 0;
+            for (int b = 0; b < nb; ++b) {
+                t0 = tt[2 * b] < t0 ? tt[2 * b] : t0;
+                t1 = tt[2 * b + 1] > t1 ? tt[2 * b + 1] : t1;
+                slast = tt[2 * b] > slast ? tt[2 * b] : slast;
+                const double l = (double)(tt[2 * b + 1] - tt[2 * b]);
+                life += l;
+                lmax = l > lmax ? l : lmax;
+            }
+            fprintf(stderr, "gemm_sprof wall (us): first start -> last end %.2f, last start at +%.2f, workgroup lifetime avg %.2f max %.2f\n", (t1 - t0) / 100.0,
+                    (slast - t0) / 100.0, life / nb / 100.0, lmax / 100.0);
+            fprintf(stderr, "gemm_sprof %dx%d w%dx%d nst%d ksub%d epi%d M=%d N=%d K=%d: (us) set-up %.2f  wait %.2f  issue %.2f  mma %.2f  epilogue %.2f  (%.0f WGs)\n", BM, BN, WM,
+                    WN, NST, KSUB, (int)epi, a.M, a.N, a.K, h[0] / n / 100, h[1] / n / 100, h[2] / n / 100, h[3] / n / 100, h[4] / n / 100, n);
+        }
+    }
+#endif
     return hipGetLastError();
 }
 
@@ -319,11 +465,16 @@ static hipError_t set_attr_cfg() {
     DINO_ATTR(EPI_QKV)
     DINO_ATTR(EPI_RESID)
     DINO_ATTR(EPI_GELU)
-    DINO_ATTR(EPI_SWIGLU)
     DINO_ATTR(EPI_PLAIN_F32)
+    if constexpr (BN / WN == 64) DINO_ATTR(EPI_SWIGLU)
 #undef DINO_ATTR
     return e;
 }
+
+#ifdef DINO_GEMM_SWEEP
+template <int BM, int BN, int WM, int WN, int NST, int KS, int KSUB>
+static void hipFuncSetAttribute_all() { (void)set_attr_cfg<_Float16, BM, BN, WM, WN, NST, KS, KSUB>(); }
+#endif
 
 hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);      // gemm2.hip, 256-row tiles
 hipError_t launch_gemm2_192(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);  // gemm2.hip, 192-row tiles
@@ -343,6 +494,12 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3>();
     if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 4, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 4, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 64, 2, 4, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 64, 2, 4, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 32, 64, 1, 4, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 32, 64, 1, 4, 3, 1, 2>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -369,7 +526,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
     if (a.kslices > 1) {  // cross-workgroup K split (tiny M, low-latency mode): the 8-wave small tile on every slice
         if (epi != EPI_PLAIN_F32 || a.bias || (a.K / 64) % 2 != 0 || !a.lda || !a.ldw) return hipErrorInvalidValue;
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st);
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st);
     }
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
@@ -380,6 +537,46 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const char* e = getenv("DINOV2_HIP_GEMM_TILE");
         return e ? atoi(e) : 0;
     }();
+#ifdef DINO_GEMM_SWEEP  // tuning builds only: DINOV2_HIP_GEMM_CFG=<n> forces one small-tile configuration (f16)
+    {
+        const char* e = getenv("DINOV2_HIP_GEMM_CFG");
+        const int c = e ? atoi(e) : -1;
+        if (c >= 0 && dt == DT_F16) {
+            switch (c) {
+#define DINO_SW(n, ...) case n: { static bool once = (hipFuncSetAttribute_all<__VA_ARGS__>(), true); (void)once; return launch_cfg<_Float16, __VA_ARGS__>(epi, a, st); }
+                DINO_SW(0, 64, 128, 2, 2, 2, 1, 1)
+                DINO_SW(1, 64, 128, 2, 2, 3, 1, 1)
+                DINO_SW(2, 64, 128, 4, 2, 3, 1, 2)
+                DINO_SW(3, 64, 128, 4, 2, 6, 1, 1)
+                DINO_SW(4, 64, 128, 4, 2, 3, 1, 1)
+                DINO_SW(5, 64, 128, 4, 2, 4, 1, 1)
+                DINO_SW(6, 128, 128, 4, 2, 2, 1, 1)
+                DINO_SW(7, 128, 128, 4, 2, 3, 1, 1)
+                DINO_SW(8, 128, 128, 4, 2, 4, 1, 1)
+                DINO_SW(9, 192, 128, 4, 2, 3, 1, 1)
+                DINO_SW(10, 192, 128, 4, 2, 4, 1, 1)
+                DINO_SW(11, 64, 128, 2, 2, 6, 1, 1)
+                DINO_SW(12, 128, 128, 2, 2, 2, 1, 1)
+                DINO_SW(13, 64, 128, 2, 2, 4, 1, 1)
+                DINO_SW(14, 128, 128, 4, 2, 5, 1, 1)
+                DINO_SW(15, 64, 128, 2, 4, 3, 1, 2)
+                DINO_SW(16, 64, 128, 2, 4, 3, 1, 1)
+                DINO_SW(17, 128, 128, 2, 4, 2, 1, 1)
+                DINO_SW(18, 128, 128, 2, 2, 3, 1, 1)
+                DINO_SW(19, 128, 128, 2, 4, 3, 1, 1)
+                DINO_SW(20, 64, 64, 2, 2, 3, 1, 2)
+                DINO_SW(21, 64, 64, 2, 4, 3, 1, 2)
+                DINO_SW(22, 32, 128, 1, 4, 3, 1, 2)
+                DINO_SW(23, 32, 64, 1, 4, 3, 1, 2)
+                DINO_SW(24, 32, 64, 2, 2, 3, 1, 2)
+                DINO_SW(25, 64, 64, 2, 2, 4, 1, 2)
+                DINO_SW(26, 64, 64, 2, 2, 3, 1, 1)
+#undef DINO_SW
+                default: return hipErrorInvalidValue;
+            }
+        }
+    }
+#endif
     // N not a multiple of 256 (ViT-S: 384, 1 152): the persistent kernel takes the leading multiple of 256 columns, the small-tile
     // kernel the remaining ones (two launches; every kernel gives a row the same bits, so the cut is invisible in the results).
     // Only where the persistent part fills the chip; not for the patch / SwiGLU epilogues (row -> token scatter indexed with N,
@@ -467,14 +664,22 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     // (never for the tail of a large launch -- small_only -- or a large batch's last rows would be summed in another order than its first)
     if (a.allow_ksplit && !a.small_only && cfg == 2 && t64 < 256 && a.K >= 1024 && (a.K / 64) % 2 == 0)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3, 2>(epi, a, st);
-    // The same few-tile shapes when the summation order must not depend on the batch size (the default): EIGHT waves on the same
-    // 64 x 128 tile (4 x 2 wave tiles of 16 x 64).  Nothing about the arithmetic changes -- each output's MFMA chain runs over K in the
-    // same order, so the bits are those of every other kernel -- but the serial part of a K step (issuing the workgroup's 24 LDS-DMA
-    // pieces, the fragment reads, the MFMAs) is spread over twice the waves: at M = 1 374 FFN-out 32.9 -> 28.3 us (split-K: 27.1),
-    // attn-out 12.6 -> 11.2 (10.8), ViT-B attn-out 10.6 -> 9.1.  With more tiles per CU (QKV, FFN-in) co-resident workgroups already
-    // overlap each other and the 8-wave tile is slower (17.7 -> 22.5, 20.1 -> 26.2 us): not used there.
-    // (two 64-wide K sub-tiles per LDS stage where K allows: half the wait / barrier links of the serial K loop, 2-6 % at M = 261 ... 1 374)
-    if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)
+    // The same few-tile shapes when the summation order must not depend on the batch size (the default).  One workgroup per CU walks
+    // a serial K loop (wait -> barrier -> issue -> fragment reads -> MFMAs per stage) and nothing overlaps it, so what counts is how
+    // short one link is (profiles/r03_small_m_gemm.md):
+    //  * eight waves, two 64-wide K sub-tiles per LDS stage (half the links);
+    //  * wave tiles of 32 x 32 (2 x 4 waves) rather than 16 x 64 (4 x 2): the loop is bound by LDS reads -- a 16 x 64 wave tile reads
+    //    five 1 KiB fragments per four MFMAs, a 32 x 32 one four -- and the LDS moves 128 B/clk (FFN-out at M = 1 374: 28.0 -> 25.4 us);
+    //  * the SMALLEST tile that still gives at most one workgroup per CU: every CU that joins shortens everybody's chain (M = 261:
+    //    attn-out 9.8 -> 5.7 us, FFN-out 27.3 -> 14.5 on 32 x 64 tiles; QKV 8.9 -> 6.3 on 64 x 64); two workgroups per CU lose again.
+    // Nothing about the arithmetic changes -- each output's MFMA chain runs over K in the same order in every configuration.
+    if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256 && epi != EPI_SWIGLU) {
+        const long t6464 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64), t3264 = (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
+        if (t3264 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 32, 64, 1, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 32, 64, 1, 4, 3, 1, 2>(epi, a, st);
+        if (t6464 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 64, 64, 2, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 64, 2, 4, 3, 1, 2>(epi, a, st);
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st);
+    }
+    if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)  // (SwiGLU pairs columns inside a 64-wide wave tile)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st);
     if (cfg == 2 && t64 < 256)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);

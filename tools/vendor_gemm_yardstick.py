@@ -3,12 +3,13 @@
 random operands, warm clocks) reaches on the forward's four GEMM shapes at ViT-L/14 batch 32 on this box, next to this library's
 kernels WITH their epilogues (tools/kernel_bench.py).  The product never calls a BLAS; this only says how much headroom a
 state-of-the-art library leaves on the same shapes.    python tools/vendor_gemm_yardstick.py"""
+import sys
 import time
 import torch
 
 torch.cuda.init()
 dev = "cuda"
-M = 32 * 1374
+M = (int(sys.argv[1]) if len(sys.argv) > 1 else 32) * 1374  # optional argument: batch size
 shapes = [("qkv", M, 3072, 1024), ("attn_out", M, 1024, 1024), ("ffn_in", M, 4096, 1024), ("ffn_out", M, 1024, 4096), ("4096^3", 4096, 4096, 4096)]
 for dt in (torch.float16, torch.bfloat16):
     for name, m, n, k in shapes:
