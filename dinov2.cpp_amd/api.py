@@ -136,7 +136,6 @@ def lib():
     fp = C.POINTER(C.c_float)
     L.dinov2_hip_op_gemm.argtypes = [i32, i32, fp, fp, fp, fp, C.c_int64, fp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                      C.c_float]
-    L.dinov2_hip_op_gemm_ksplit.argtypes = L.dinov2_hip_op_gemm.argtypes
     L.dinov2_hip_op_attention.argtypes = [i32, fp, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_layernorm.argtypes = [i32, fp, fp, fp, fp, i32, i32, C.c_float]
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
@@ -145,8 +144,6 @@ def lib():
     L.dinov2_hip_op_preprocess_u8.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     L.dinov2_hip_op_gemm_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_gemm_bench.restype = C.c_float
-    L.dinov2_hip_op_gemm_bench_ksplit.argtypes = [i32] * 6
-    L.dinov2_hip_op_gemm_bench_ksplit.restype = C.c_float
     L.dinov2_hip_op_attention_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_attention_bench.restype = C.c_float
     _lib = L

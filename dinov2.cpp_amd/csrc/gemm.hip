@@ -23,11 +23,6 @@
 
 namespace dinov2 {
 
-// KS = 2: intra-workgroup split-K for the few-tile, long-K GEMMs of a small batch.  The workgroup is TWO wave groups of WM x WN
-// waves; group g multiplies K-tiles [g nk/2, (g+1) nk/2) of the SAME output tile out of its own LDS ring, both in step (shared
-// barriers), and at the end group 1 hands its accumulators to group 0 through LDS: result = acc_lo + acc_hi, one extra f32
-// rounding against the un-split sum.  No global traffic, no extra launch, deterministic -- but not the bits of the un-split
-// kernel, so it is used only when the caller allows it (GemmArgs.allow_ksplit; dinov2_hip_load_opts.batch_invariant = 0).
 // KSUB = 64-wide K sub-tiles per LDS stage (1, or 2 for the few-tile shapes of a small batch: their K loop is a serial chain of
 // wait -> barrier -> issue -> read -> MFMA per stage, and a stage twice as deep halves the number of links; same K order).
 // -DDINO_GEMM_SPROF (tuning builds): wall-clock (100 MHz) sums of wave 0 of every workgroup -- [0] set-up and the first stages' issue, [1] counted
@@ -38,15 +33,15 @@ __device__ unsigned long long g_sprof_t[2 * 1024];  // wall clock (100 MHz) at e
 #define DINO_SP_INIT const unsigned long long sp_w0 = wall_clock64(); unsigned long long sp_t = sp_w0, sp_acc[5] = {0, 0, 0, 0, 0};
 #define DINO_SP(i) { const unsigned long long t__ = wall_clock64(); sp_acc[i] += t__ - sp_t; sp_t = t__; }
 #define DINO_SP_FLUSH if (tid == 0) { for (int i__ = 0; i__ < 5; ++i__) atomicAdd(&g_sprof[i__], sp_acc[i__]); atomicAdd(&g_sprof[5], 1ull); \
-        if (blockIdx.x < 1024 && blockIdx.y == 0) { g_sprof_t[2 * blockIdx.x] = sp_w0; g_sprof_t[2 * blockIdx.x + 1] = wall_clock64(); } }
+        if (blockIdx.x < 1024) { g_sprof_t[2 * blockIdx.x] = sp_w0; g_sprof_t[2 * blockIdx.x + 1] = wall_clock64(); } }
 #else
 #define DINO_SP_INIT
 #define DINO_SP(i)
 #define DINO_SP_FLUSH
 #endif
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI, int KS = 1, int KSUB = 1>
-__global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
+template <typename T, int BM, int BN, int WM, int WN, int NST, int EPI, int KSUB = 1>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma clang fp contract(off)  // position-independent results: see gemm2.hip
     using E = Elem<T>;
     using vec8 = typename E::vec8;
@@ -65,14 +60,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = KS == 1 ? 0 : wid_all / NW;  // K-split group
-    const int wid = KS == 1 ? wid_all : wid_all - grp * NW;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = p.M, N = p.N, K = p.K;
     const size_t lda = p.lda ? p.lda : K, ldw = p.ldw ? p.ldw : K;
 
     const int ntn = (N + BN - 1) / BN, ntm = (M + BM - 1) / BM;
-    const size_t kslice = blockIdx.y;  // K slice of a cross-workgroup split (GemmArgs.kslices; 0 otherwise)
     const int lid = xcd_remap(blockIdx.x, ntn * ntm);
     const int m0 = (lid / ntn) * BM, n0 = (lid % ntn) * BN;
 
@@ -86,7 +78,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gm = m0 + row;
         gm = gm < M ? gm : M - 1;
-        asrc[j] = (const char*)p.A + ((size_t)gm * lda + kslice * (size_t)K) * 2 + lc * 16;
+        asrc[j] = (const char*)p.A + ((size_t)gm * lda) * 2 + lc * 16;
     }
 #pragma unroll
     for (int j = 0; j < BI; ++j) {
@@ -94,17 +86,16 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         int gn = n0 + row;
         gn = gn < N ? gn : N - 1;
-        bsrc[j] = (const char*)p.W + ((size_t)gn * ldw + kslice * (size_t)K) * 2 + lc * 16;
+        bsrc[j] = (const char*)p.W + ((size_t)gn * ldw) * 2 + lc * 16;
     }
 
-    char* const smem = smem_all + grp * (NST * STAGE);  // this group's LDS ring
-    const int kt_lo = grp * ((K / BK) / KS);            // this group's K range (the launcher guarantees (K / 64) % (KS * KSUB) == 0)
+    char* const smem = smem_all;  // the LDS ring (the launcher guarantees (K / 64) % KSUB == 0)
     auto stage = [&](int buf, int kt) {
 #pragma unroll
         for (int sb = 0; sb < KSUB; ++sb) {
             char* sA = smem + buf * STAGE + sb * SUBT;
             char* sB = sA + BM * ROWB;
-            const size_t koff = (size_t)(kt_lo + kt * KSUB + sb) * (BK * 2);
+            const size_t koff = (size_t)(kt * KSUB + sb) * (BK * 2);
 #pragma unroll
             for (int j = 0; j < AI; ++j) glds16(asrc[j] + koff, sA + (j * NW + wid) * 8 * ROWB);
 #pragma unroll
@@ -157,7 +148,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     // done reading the buffer that tile kt+NST-1 is about to overwrite.  Raw s_barrier: __syncthreads() would drain vmcnt.
     constexpr int LPT = KSUB * (AI + BI);  // glds instructions per wave per stage
     static_assert((NST - 2) * LPT < 64, "vmcnt is 6 bits");
-    const int nk = (K / BK) / KS / KSUB;
+    const int nk = (K / BK) / KSUB;
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
@@ -198,30 +189,6 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
         asm volatile("s_nop 0" : "+v"(acc[0][0]));  // the section ends when the last MFMA chain's first link has issued, not retired
 #endif
         DINO_SP(3)
-    }
-
-    if constexpr (KS == 2) {
-        // group 1 -> LDS -> group 0: element (wave, accumulator register q) of lane l at float index (wave * NQ + q) * 64 + l
-        constexpr int NQ = MREP * NREP * 4;
-        static_assert(NW * NQ * 256 <= NST * STAGE, "the hand-over buffer reuses group 0's ring");
-        float* const xch = (float*)smem_all + (size_t)wid * NQ * 64 + lane;
-        __syncthreads();  // every wave has finished its last fragment reads: group 0's ring is free
-        if (grp == 1) {
-#pragma unroll
-            for (int i = 0; i < MREP; ++i)
-#pragma unroll
-                for (int j = 0; j < NREP; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) xch[((i * NREP + j) * 4 + r) * 64] = acc[i][j][r];
-        }
-        __syncthreads();
-        if (grp == 1) return;
-#pragma unroll
-        for (int i = 0; i < MREP; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += xch[((i * NREP + j) * 4 + r) * 64];  // acc_lo + acc_hi
     }
 
     // ---- epilogue: acc[i][j][r] is C[row, col] with
@@ -283,7 +250,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                     const f32x4 xi = xin4[i][jn], au = aux4[jn];
                     *(f32x4*)x = f32x4{v[0] * au[0] + xi[0], v[1] * au[1] + xi[1], v[2] * au[2] + xi[2], v[3] * au[3] + xi[3]};
                 } else if constexpr (EPI == EPI_PLAIN_F32) {
-                    float* x = (float*)p.out + kslice * p.kslice_ostride + (size_t)row * p.ldo + col0;
+                    float* x = (float*)p.out + (size_t)row * p.ldo + col0;
                     *(f32x4*)x = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
                     typename E::vec4 o;
@@ -359,7 +326,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
                             if (col0 + r < N) x[col0 + r] = v[r] * auxv[r] + x[col0 + r];
                     }
                 } else if constexpr (EPI == EPI_PLAIN_F32) {
-                    float* x = (float*)p.out + kslice * p.kslice_ostride + (size_t)row * p.ldo;
+                    float* x = (float*)p.out + (size_t)row * p.ldo;
                     if (full) *(float4*)(x + col0) = make_float4(v[0], v[1], v[2], v[3]);
                     else {
 #pragma unroll
@@ -400,14 +367,14 @@ __global__ __launch_bounds__(WM * WN * 64 * KS) void gemm_kernel(GemmArgs p) {
     DINO_SP_FLUSH
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1, int KSUB = 1>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KSUB = 1>
 static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
-    const dim3 grid(ntn * ntm, a.kslices > 1 ? a.kslices : 1), block(WM * WN * 64 * KS);
-    const size_t lds = KS * NST * KSUB * (size_t)(BM + BN) * 128;
+    const dim3 grid(ntn * ntm), block(WM * WN * 64);
+    const size_t lds = NST * KSUB * (size_t)(BM + BN) * 128;
 #define DINO_LAUNCH(E)                                                                             \
     case E:                                                                                        \
-        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E, KS, KSUB>), grid, block, lds, st, a); \
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E, KSUB>), grid, block, lds, st, a); \
         break;
     switch (epi) {
         DINO_LAUNCH(EPI_PATCH)
@@ -416,7 +383,7 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         DINO_LAUNCH(EPI_GELU)
         DINO_LAUNCH(EPI_PLAIN_F32)
         case EPI_SWIGLU:  // (its column pairing needs 64-wide wave tiles)
-            if constexpr (BN / WN == 64) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, EPI_SWIGLU, KS, KSUB>), grid, block, lds, st, a);
+            if constexpr (BN / WN == 64) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, EPI_SWIGLU, KSUB>), grid, block, lds, st, a);
             else return hipErrorInvalidValue;
             break;
     }
@@ -453,13 +420,13 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int NST, int KS = 1, int KSUB = 1>
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KSUB = 1>
 static hipError_t set_attr_cfg() {
-    const int lds = KS * NST * KSUB * (BM + BN) * 128;
+    const int lds = NST * KSUB * (BM + BN) * 128;
     hipError_t e = hipSuccess;
 #define DINO_ATTR(E)                                                                                          \
     if (e == hipSuccess)                                                                                      \
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E, KS, KSUB>),  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, BM, BN, WM, WN, NST, E, KSUB>),  \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     DINO_ATTR(EPI_PATCH)
     DINO_ATTR(EPI_QKV)
@@ -472,8 +439,8 @@ static hipError_t set_attr_cfg() {
 }
 
 #ifdef DINO_GEMM_SWEEP
-template <int BM, int BN, int WM, int WN, int NST, int KS, int KSUB>
-static void hipFuncSetAttribute_all() { (void)set_attr_cfg<_Float16, BM, BN, WM, WN, NST, KS, KSUB>(); }
+template <int BM, int BN, int WM, int WN, int NST, int KSUB>
+static void hipFuncSetAttribute_all() { (void)set_attr_cfg<_Float16, BM, BN, WM, WN, NST, KSUB>(); }
 #endif
 
 hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);      // gemm2.hip, 256-row tiles
@@ -488,18 +455,16 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 2>();
     if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 3>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 2, 3, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 2, 3, 2>();
     if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3>();
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 4, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 4, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 64, 2, 4, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 64, 2, 4, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<_Float16, 32, 64, 1, 4, 3, 1, 2>();
-    if (e == hipSuccess) e = set_attr_cfg<__bf16, 32, 64, 1, 4, 3, 1, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 4, 2, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 4, 2, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 128, 2, 4, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 128, 2, 4, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 64, 64, 2, 4, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 64, 64, 2, 4, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<_Float16, 32, 64, 1, 4, 3, 2>();
+    if (e == hipSuccess) e = set_attr_cfg<__bf16, 32, 64, 1, 4, 3, 2>();
     if (e == hipSuccess) e = gemm2_init();
     return e;
 }
@@ -524,10 +489,6 @@ hipError_t gemm_init() {
 // 221 -> 244 images/s.  DINOV2_HIP_GEMM_TILE=128|256 forces E / A (testing aid: include/dinov2_hip.h, "Environment").
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    if (a.kslices > 1) {  // cross-workgroup K split (tiny M, low-latency mode): the 8-wave small tile on every slice
-        if (epi != EPI_PLAIN_F32 || a.bias || (a.K / 64) % 2 != 0 || !a.lda || !a.ldw) return hipErrorInvalidValue;
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st);
-    }
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
     // rows are fetched with 16-byte global -> LDS DMA pieces and 16-byte vector loads: strides must keep rows 16-byte aligned
@@ -544,33 +505,33 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         if (c >= 0 && dt == DT_F16) {
             switch (c) {
 #define DINO_SW(n, ...) case n: { static bool once = (hipFuncSetAttribute_all<__VA_ARGS__>(), true); (void)once; return launch_cfg<_Float16, __VA_ARGS__>(epi, a, st); }
-                DINO_SW(0, 64, 128, 2, 2, 2, 1, 1)
-                DINO_SW(1, 64, 128, 2, 2, 3, 1, 1)
-                DINO_SW(2, 64, 128, 4, 2, 3, 1, 2)
-                DINO_SW(3, 64, 128, 4, 2, 6, 1, 1)
-                DINO_SW(4, 64, 128, 4, 2, 3, 1, 1)
-                DINO_SW(5, 64, 128, 4, 2, 4, 1, 1)
-                DINO_SW(6, 128, 128, 4, 2, 2, 1, 1)
-                DINO_SW(7, 128, 128, 4, 2, 3, 1, 1)
-                DINO_SW(8, 128, 128, 4, 2, 4, 1, 1)
-                DINO_SW(9, 192, 128, 4, 2, 3, 1, 1)
-                DINO_SW(10, 192, 128, 4, 2, 4, 1, 1)
-                DINO_SW(11, 64, 128, 2, 2, 6, 1, 1)
-                DINO_SW(12, 128, 128, 2, 2, 2, 1, 1)
-                DINO_SW(13, 64, 128, 2, 2, 4, 1, 1)
-                DINO_SW(14, 128, 128, 4, 2, 5, 1, 1)
-                DINO_SW(15, 64, 128, 2, 4, 3, 1, 2)
-                DINO_SW(16, 64, 128, 2, 4, 3, 1, 1)
-                DINO_SW(17, 128, 128, 2, 4, 2, 1, 1)
-                DINO_SW(18, 128, 128, 2, 2, 3, 1, 1)
-                DINO_SW(19, 128, 128, 2, 4, 3, 1, 1)
-                DINO_SW(20, 64, 64, 2, 2, 3, 1, 2)
-                DINO_SW(21, 64, 64, 2, 4, 3, 1, 2)
-                DINO_SW(22, 32, 128, 1, 4, 3, 1, 2)
-                DINO_SW(23, 32, 64, 1, 4, 3, 1, 2)
-                DINO_SW(24, 32, 64, 2, 2, 3, 1, 2)
-                DINO_SW(25, 64, 64, 2, 2, 4, 1, 2)
-                DINO_SW(26, 64, 64, 2, 2, 3, 1, 1)
+                DINO_SW(0, 64, 128, 2, 2, 2, 1)
+                DINO_SW(1, 64, 128, 2, 2, 3, 1)
+                DINO_SW(2, 64, 128, 4, 2, 3, 2)
+                DINO_SW(3, 64, 128, 4, 2, 6, 1)
+                DINO_SW(4, 64, 128, 4, 2, 3, 1)
+                DINO_SW(5, 64, 128, 4, 2, 4, 1)
+                DINO_SW(6, 128, 128, 4, 2, 2, 1)
+                DINO_SW(7, 128, 128, 4, 2, 3, 1)
+                DINO_SW(8, 128, 128, 4, 2, 4, 1)
+                DINO_SW(9, 192, 128, 4, 2, 3, 1)
+                DINO_SW(10, 192, 128, 4, 2, 4, 1)
+                DINO_SW(11, 64, 128, 2, 2, 6, 1)
+                DINO_SW(12, 128, 128, 2, 2, 2, 1)
+                DINO_SW(13, 64, 128, 2, 2, 4, 1)
+                DINO_SW(14, 128, 128, 4, 2, 5, 1)
+                DINO_SW(15, 64, 128, 2, 4, 3, 2)
+                DINO_SW(16, 64, 128, 2, 4, 3, 1)
+                DINO_SW(17, 128, 128, 2, 4, 2, 1)
+                DINO_SW(18, 128, 128, 2, 2, 3, 1)
+                DINO_SW(19, 128, 128, 2, 4, 3, 1)
+                DINO_SW(20, 64, 64, 2, 2, 3, 2)
+                DINO_SW(21, 64, 64, 2, 4, 3, 2)
+                DINO_SW(22, 32, 128, 1, 4, 3, 2)
+                DINO_SW(23, 32, 64, 1, 4, 3, 2)
+                DINO_SW(24, 32, 64, 2, 2, 3, 2)
+                DINO_SW(25, 64, 64, 2, 2, 4, 2)
+                DINO_SW(26, 64, 64, 2, 2, 3, 1)
 #undef DINO_SW
                 default: return hipErrorInvalidValue;
             }
@@ -658,13 +619,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     const long t64 = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
     const int cfg = t128 >= 512 ? 0 : t64 >= 384 ? 1 : 2;
-    // Fewer tiles than CUs and a long K loop (batch 1: the two N = hidden GEMMs, 176 tiles, 16 / 64 K-tiles): one wave per SIMD
-    // walks a serial, latency-bound K loop.  Split K inside the workgroup (KS = 2, see gemm_kernel) when the caller allows a
-    // summation order that depends on the batch size: FFN-out 33.7 -> 25.3 us, attn-out 13.8 -> 9.8 us at M = 1 374 (ViT-L p50 3.03 -> 2.79 ms).
-    // (never for the tail of a large launch -- small_only -- or a large batch's last rows would be summed in another order than its first)
-    if (a.allow_ksplit && !a.small_only && cfg == 2 && t64 < 256 && a.K >= 1024 && (a.K / 64) % 2 == 0)
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3, 2>(epi, a, st);
-    // The same few-tile shapes when the summation order must not depend on the batch size (the default).  One workgroup per CU walks
+    // Fewer tiles than CUs (batch 1: the two N = hidden GEMMs at 518 x 518, every GEMM at 224 x 224): one workgroup per CU walks
     // a serial K loop (wait -> barrier -> issue -> fragment reads -> MFMAs per stage) and nothing overlaps it, so what counts is how
     // short one link is (profiles/r03_small_m_gemm.md):
     //  * eight waves, two 64-wide K sub-tiles per LDS stage (half the links);
@@ -675,12 +630,12 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
     // Nothing about the arithmetic changes -- each output's MFMA chain runs over K in the same order in every configuration.
     if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256 && epi != EPI_SWIGLU) {
         const long t6464 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64), t3264 = (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
-        if (t3264 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 32, 64, 1, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 32, 64, 1, 4, 3, 1, 2>(epi, a, st);
-        if (t6464 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 64, 64, 2, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 64, 2, 4, 3, 1, 2>(epi, a, st);
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 4, 3, 1, 2>(epi, a, st);
+        if (t3264 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 32, 64, 1, 4, 3, 2>(epi, a, st) : launch_cfg<__bf16, 32, 64, 1, 4, 3, 2>(epi, a, st);
+        if (t6464 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 64, 64, 2, 4, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 64, 2, 4, 3, 2>(epi, a, st);
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 4, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 4, 3, 2>(epi, a, st);
     }
     if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)  // (SwiGLU pairs columns inside a 64-wide wave tile)
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 1, 2>(epi, a, st);
+        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 2>(epi, a, st);
     if (cfg == 2 && t64 < 256)
         return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);
     if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);

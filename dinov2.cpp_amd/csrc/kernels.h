@@ -32,11 +32,6 @@ struct GemmArgs {
     int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale
     float qscale;
     int small_only;     // launch_gemm internal: this is the tail of a split launch, use the small-tile kernel
-    int allow_ksplit;   // 1: few-tile, long-K shapes may split K inside the workgroup (result = acc_lo + acc_hi: deterministic, but
-                        // not the bits of the un-split sum).  0 (default): every kernel sums K in the same order.
-    int kslices;        // > 1 (EPI_PLAIN_F32 only, tiny M): K is cut into `kslices` equal slices ACROSS workgroups (grid.y); K is the
-                        // slice length, lda / ldw the full row strides, slice s writes its partial products to out + s * kslice_ostride
-    size_t kslice_ostride;  // elements
 };
 
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);
@@ -49,12 +44,6 @@ hipError_t launch_layernorm(DType dt, const float* x, const float* w, const floa
 // same, f32 output (final layernorm)
 hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int H, float eps,
                                 hipStream_t stream);
-// The residual epilogue of a K-sliced GEMM fused into the LayerNorm that follows it (tiny M, low-latency mode):
-//   x[r, :] += ls * ((((p_0 + p_1) + p_2) ... + p_{S-1}) + bias)   (the slices in a fixed order), then LayerNorm of the new row.
-// parts: [S][rows][H] f32 partial products; y: T (f32_out = 0) or float (f32_out = 1).
-hipError_t launch_layernorm_reduce(DType dt, int f32_out, float* x, const float* parts, int S, const float* bias, const float* ls,
-                                   const float* w, const float* b, void* y, int rows, int H, float eps, hipStream_t stream);
-
 // fused multi-head attention over token-major qkv [B*T, 3H] (T dtype, q pre-scaled), out [B*T, H]; hd == 64.
 // log2_scores: q was scaled by log2(e)/sqrt(hd) instead of 1/sqrt(hd), so softmax uses exp2 directly.
 hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,

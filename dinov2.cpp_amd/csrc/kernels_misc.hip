@@ -99,91 +99,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-// LayerNorm with the residual epilogue of a K-sliced GEMM in front (launch_layernorm_reduce): the row's new value
-// x + ls * ((p_0 + p_1 + ... in slice order) + bias) is formed in registers, written back, and normalised.
-template <typename OutT, int MAXV>
-__global__ __launch_bounds__(256) void layernorm_reduce_kernel(float* __restrict__ x, const float* __restrict__ parts, int S,
-                                                               const float* __restrict__ bias, const float* __restrict__ ls,
-                                                               const float* __restrict__ w, const float* __restrict__ bta,
-                                                               OutT* __restrict__ y, int rows, int H, float eps) {
-#pragma clang fp contract(off)
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int nv = H >> 2;
-    float4* xr = (float4*)(x + (size_t)row * H);
-    const size_t pstride = (size_t)rows * H;
-    float4 v[MAXV];
-    double sum = 0.0;
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nv) {
-            float4 a = ((const float4*)(parts + (size_t)row * H))[i];
-            for (int s = 1; s < S; ++s) {
-                const float4 q = ((const float4*)(parts + s * pstride + (size_t)row * H))[i];
-                a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
-            }
-            const float4 bb = ((const float4*)bias)[i], l4 = ((const float4*)ls)[i], x0 = xr[i];
-            // the expression of the GEMMs' residual epilogue: (acc + bias) * ls + x
-            v[j] = make_float4((a.x + bb.x) * l4.x + x0.x, (a.y + bb.y) * l4.y + x0.y, (a.z + bb.z) * l4.z + x0.z, (a.w + bb.w) * l4.w + x0.w);
-            xr[i] = v[j];
-            sum += (double)v[j].x + (double)v[j].y + (double)v[j].z + (double)v[j].w;
-        }
-    }
-    sum = wave_sum_f64(sum);
-    const float mean = (float)(sum / H);
-    double sq = 0.0;
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nv) {
-            v[j].x -= mean; v[j].y -= mean; v[j].z -= mean; v[j].w -= mean;
-            sq += (double)(v[j].x * v[j].x) + (double)(v[j].y * v[j].y) + (double)(v[j].z * v[j].z) + (double)(v[j].w * v[j].w);
-        }
-    }
-    sq = wave_sum_f64(sq);
-    const float var = (float)(sq / H);
-    const float scale = 1.0f / sqrtf(var + eps);
-#pragma unroll
-    for (int j = 0; j < MAXV; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nv) {
-            const float4 ww = ((const float4*)w)[i], bb = ((const float4*)bta)[i];
-            float r0 = v[j].x * scale * ww.x + bb.x, r1 = v[j].y * scale * ww.y + bb.y;
-            float r2 = v[j].z * scale * ww.z + bb.z, r3 = v[j].w * scale * ww.w + bb.w;
-            asm("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3));  // f32 result first, f16 rounding second (as layernorm_kernel)
-            if constexpr (sizeof(OutT) == 4) {
-                ((float4*)(y + (size_t)row * H))[i] = make_float4(r0, r1, r2, r3);
-            } else {
-                typedef OutT o4 __attribute__((ext_vector_type(4)));
-                o4 pk;
-                pk[0] = (OutT)r0; pk[1] = (OutT)r1; pk[2] = (OutT)r2; pk[3] = (OutT)r3;
-                ((o4*)(y + (size_t)row * H))[i] = pk;
-            }
-        }
-    }
-}
-
-template <typename OutT>
-static hipError_t lnr_dispatch(float* x, const float* parts, int S, const float* bias, const float* ls, const float* w, const float* b,
-                               OutT* y, int rows, int H, float eps, hipStream_t st) {
-    if (H % 4 != 0 || H > 64 * 4 * 8 || S < 1) return hipErrorInvalidValue;
-    const dim3 grid((rows + 3) / 4), block(256);
-    const int nv = (H / 4 + 63) / 64;
-    if (nv <= 2) hipLaunchKernelGGL((layernorm_reduce_kernel<OutT, 2>), grid, block, 0, st, x, parts, S, bias, ls, w, b, y, rows, H, eps);
-    else if (nv <= 4) hipLaunchKernelGGL((layernorm_reduce_kernel<OutT, 4>), grid, block, 0, st, x, parts, S, bias, ls, w, b, y, rows, H, eps);
-    else hipLaunchKernelGGL((layernorm_reduce_kernel<OutT, 8>), grid, block, 0, st, x, parts, S, bias, ls, w, b, y, rows, H, eps);
-    return hipGetLastError();
-}
-
-hipError_t launch_layernorm_reduce(DType dt, int f32_out, float* x, const float* parts, int S, const float* bias, const float* ls,
-                                   const float* w, const float* b, void* y, int rows, int H, float eps, hipStream_t st) {
-    if (f32_out) return lnr_dispatch<float>(x, parts, S, bias, ls, w, b, (float*)y, rows, H, eps, st);
-    return dt == DT_F16 ? lnr_dispatch<_Float16>(x, parts, S, bias, ls, w, b, (_Float16*)y, rows, H, eps, st)
-                        : lnr_dispatch<__bf16>(x, parts, S, bias, ls, w, b, (__bf16*)y, rows, H, eps, st);
-}
-
 template <typename OutT>
 static hipError_t ln_dispatch(const float* x, const float* w, const float* b, OutT* y, int rows, int H, float eps,
                               hipStream_t st) {

@@ -211,7 +211,6 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
     m->device = opts.device;
     m->quirk_const_div = opts.quirk_pool_const_divisor != 0;
     m->quirk_pool_regs = opts.quirk_pool_includes_registers != 0;
-    m->batch_invariant = opts.batch_invariant != 0;
 
     const int H = (int)hp.hidden_size, L = (int)hp.num_hidden_layers, nh = (int)hp.num_attention_heads;
     const int ps = (int)hp.patch_size, R = (int)hp.num_register_tokens;
@@ -453,26 +452,8 @@ Dims dims_of(const dinov2_hip_model* m, int B, int h, int w) {
 }
 
 struct Carve {
-    size_t img, col, x, ln, qkv, att, hid, fin, feat, logits, probs, pos, part, part_bytes, total;
+    size_t img, col, x, ln, qkv, att, hid, fin, feat, logits, probs, pos, total;
 };
-
-// Low-latency mode (batch_invariant = 0), tiny M: the FFN-out GEMM (K = ffn_hidden: 64 serial K-tiles on ~40 workgroups at T = 261)
-// is cut along K ACROSS workgroups and its residual epilogue moves into the LayerNorm that follows.  Slices, or 0 = not used.
-int ffn_out_kslices(const dinov2_hip_model* m, int M) {
-    if (m->batch_invariant || M > 512) return 0;
-    const int F = (int)m->hp.ffn_hidden;
-    if (F < 1536 || F % 512 != 0) return 0;
-    const int s = F >= 2048 ? F / 1024 : F / 512;  // >= 8 K-tiles per slice
-    return (s >= 2 && s <= 8 && F % s == 0 && (F / s) % 128 == 0) ? s : 0;
-}
-// the same for the attention output projection (K = hidden, followed by norm2): slices of 512 (ViT-L, ViT-g) or 256 (ViT-B)
-int attn_out_kslices(const dinov2_hip_model* m, int M) {
-    if (m->batch_invariant || M > 512) return 0;
-    const int H = (int)m->hp.hidden_size;
-    if (H < 768) return 0;
-    const int len = H % 512 == 0 ? 512 : H % 256 == 0 ? 256 : 0;
-    return len && H / len >= 2 && H / len <= 8 ? H / len : 0;
-}
 
 Carve carve_of(const dinov2_hip_model* m, int B, int h, int w) {
     const Dims d = dims_of(m, B, h, w);
@@ -496,8 +477,6 @@ Carve carve_of(const dinov2_hip_model* m, int B, int h, int w) {
     c.logits = put(sizeof(float) * (size_t)B * C);
     c.probs = put(sizeof(float) * (size_t)B * C);
     c.pos = put(sizeof(float) * (size_t)(1 + d.P) * H);
-    c.part_bytes = sizeof(float) * (size_t)std::max(ffn_out_kslices(m, d.M), attn_out_kslices(m, d.M)) * d.M * H;
-    c.part = put(c.part_bytes);
     c.total = off;
     return c;
 }
@@ -528,7 +507,6 @@ int ensure_workspace(dinov2_hip_session* s, int B, int h, int w, char* err, size
     s->logits = (float*)(s->ws + c.logits);
     s->probs = (float*)(s->ws + c.probs);
     s->pos = (float*)(s->ws + c.pos);
-    s->part = c.part_bytes ? (float*)(s->ws + c.part) : nullptr;
     s->pos_h = s->pos_w = -1;  // the carve moved: re-upload the pos-embed
     s->cur_b = B;
     s->cur_h = h;
@@ -632,20 +610,11 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         HIP_TRY(launch_gemm(dt, EPI_PATCH, a, st));
     }
     const float eps = m->hp.eps;
-    // K-sliced FFN-out (see ffn_out_kslices): the GEMM leaves partial products in s->part, and the NEXT LayerNorm launch -- norm1 of
-    // the following layer, or the final LayerNorm -- applies bias, LayerScale and the residual add before it normalises.
-    const int kslices = s->part ? ffn_out_kslices(m, d.M) : 0, aslices = s->part ? attn_out_kslices(m, d.M) : 0;
-    const LayerWeights* pending = nullptr;  // layer whose FFN-out result is still in s->part
     for (int il = 0; il < nlayers; ++il) {
         const LayerWeights& ly = m->layers[(size_t)il];
         {
             Scope sc(s, K_LAYERNORM);
-            if (pending)
-                HIP_TRY(launch_layernorm_reduce(dt, 0, s->x, s->part, kslices, pending->fc2_b, pending->ls2, ly.norm1_w, ly.norm1_b, s->ln,
-                                                d.M, H, eps, st));
-            else
-                HIP_TRY(launch_layernorm(dt, s->x, ly.norm1_w, ly.norm1_b, s->ln, d.M, H, eps, st));
-            pending = nullptr;
+            HIP_TRY(launch_layernorm(dt, s->x, ly.norm1_w, ly.norm1_b, s->ln, d.M, H, eps, st));
         }
         {
             Scope sc(s, K_QKV_GEMM);
@@ -662,21 +631,13 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_OPROJ_GEMM);
             GemmArgs a{};
-            a.A = s->att; a.W = ly.o_w; a.M = d.M; a.N = H; a.ldo = H;
-            if (aslices) {
-                a.out = s->part; a.K = H / aslices; a.lda = H; a.ldw = H; a.kslices = aslices; a.kslice_ostride = (size_t)d.M * H;
-                HIP_TRY(launch_gemm(dt, EPI_PLAIN_F32, a, st));
-            } else {
-                a.bias = ly.o_b; a.out = s->x; a.aux = ly.ls1; a.K = H; a.allow_ksplit = !m->batch_invariant;
-                HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
-            }
+            a.A = s->att; a.W = ly.o_w; a.bias = ly.o_b; a.out = s->x; a.aux = ly.ls1;
+            a.M = d.M; a.N = H; a.K = H; a.ldo = H;
+            HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
         }
         {
             Scope sc(s, K_LAYERNORM);
-            if (aslices)
-                HIP_TRY(launch_layernorm_reduce(dt, 0, s->x, s->part, aslices, ly.o_b, ly.ls1, ly.norm2_w, ly.norm2_b, s->ln, d.M, H, eps, st));
-            else
-                HIP_TRY(launch_layernorm(dt, s->x, ly.norm2_w, ly.norm2_b, s->ln, d.M, H, eps, st));
+            HIP_TRY(launch_layernorm(dt, s->x, ly.norm2_w, ly.norm2_b, s->ln, d.M, H, eps, st));
         }
         {
             Scope sc(s, K_FC1_GEMM);
@@ -688,31 +649,15 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_FC2_GEMM);
             GemmArgs a{};
-            a.A = s->hid; a.W = ly.fc2_w; a.M = d.M; a.N = H; a.ldo = H;
-            if (kslices) {
-                a.out = s->part; a.K = F / kslices; a.lda = F; a.ldw = F; a.kslices = kslices; a.kslice_ostride = (size_t)d.M * H;
-                HIP_TRY(launch_gemm(dt, EPI_PLAIN_F32, a, st));
-                pending = &ly;
-            } else {
-                a.bias = ly.fc2_b; a.out = s->x; a.aux = ly.ls2; a.K = F; a.allow_ksplit = !m->batch_invariant;
-                HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
-            }
+            a.A = s->hid; a.W = ly.fc2_w; a.bias = ly.fc2_b; a.out = s->x; a.aux = ly.ls2;
+            a.M = d.M; a.N = H; a.K = F; a.ldo = H;
+            HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
         }
     }
-    if (!finalize) {
-        if (pending) {  // (dinov2_hip_debug_hidden stops here: complete the residual stream; the normalised rows go to scratch)
-            const LayerWeights& nl = m->layers[0];
-            HIP_TRY(launch_layernorm_reduce(dt, 0, s->x, s->part, kslices, pending->fc2_b, pending->ls2, nl.norm1_w, nl.norm1_b, s->ln, d.M, H,
-                                            eps, st));
-        }
-        return DINOV2_HIP_OK;
-    }
+    if (!finalize) return DINOV2_HIP_OK;
     {
         Scope sc(s, K_FINAL_LN);
-        if (pending)
-            HIP_TRY(launch_layernorm_reduce(dt, 1, s->x, s->part, kslices, pending->fc2_b, pending->ls2, m->ln_w, m->ln_b, s->fin, d.M, H, eps, st));
-        else
-            HIP_TRY(launch_layernorm_f32(s->x, m->ln_w, m->ln_b, s->fin, d.M, H, eps, st));
+        HIP_TRY(launch_layernorm_f32(s->x, m->ln_w, m->ln_b, s->fin, d.M, H, eps, st));
     }
     if (classify) {
         Scope sc(s, K_HEAD);

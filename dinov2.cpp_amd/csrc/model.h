@@ -24,7 +24,6 @@ struct dinov2_hip_model {
     dinov2::DType dt = dinov2::DT_F16;
     int device = 0;
     bool quirk_const_div = true, quirk_pool_regs = true;
-    bool batch_invariant = true;  // dinov2_hip_load_opts.batch_invariant: never split K
     int kpe = 0, kpe_pad = 0;  // patch-embed K (3*p*p) and its padding to a multiple of 64
     char* arena = nullptr;     // ONE allocation, like model.buffer (dinov2.cpp:341)
     size_t arena_bytes = 0;
@@ -61,7 +60,6 @@ struct dinov2_hip_session {
     float *img = nullptr, *x = nullptr, *fin = nullptr, *feat = nullptr, *logits = nullptr, *probs = nullptr,
           *pos = nullptr;
     void *col = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
-    float* part = nullptr;  // K-slice partial products of the FFN-out GEMM (tiny M, low-latency mode only; else null)
     int pos_h = -1, pos_w = -1;  // grid the cached interpolated pos-embed in `pos` belongs to
     std::vector<float> pos_stage;
     // hipGraph cache (the "allocr reuse" of the reference taken one step further): a forward that repeats with the same

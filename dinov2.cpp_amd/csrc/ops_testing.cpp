@@ -67,28 +67,10 @@ hipError_t download_as(DType dt, const void* dev, size_t n, float* dst) {
 
 }  // namespace
 
-static int op_gemm_impl(int32_t dtype, int32_t epilogue, const float* A, const float* W, const float* bias, const float* aux,
-                        int64_t aux_count, float* out, int32_t out_rows, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t P,
-                        int32_t T, int32_t R, int32_t qcols, float qscale, int allow_ksplit);
-
 extern "C" int dinov2_hip_op_gemm(int32_t dtype, int32_t epilogue, const float* A, const float* W, const float* bias,
                                   const float* aux, int64_t aux_count, float* out, int32_t out_rows, int32_t ldo,
                                   int32_t M, int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols,
                                   float qscale) {
-    return op_gemm_impl(dtype, epilogue, A, W, bias, aux, aux_count, out, out_rows, ldo, M, N, K, P, T, R, qcols, qscale, 0);
-}
-
-// the same with GemmArgs.allow_ksplit = 1: few-tile, long-K shapes take the intra-workgroup split-K kernel (csrc/gemm.hip)
-extern "C" int dinov2_hip_op_gemm_ksplit(int32_t dtype, int32_t epilogue, const float* A, const float* W, const float* bias,
-                                         const float* aux, int64_t aux_count, float* out, int32_t out_rows, int32_t ldo,
-                                         int32_t M, int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols,
-                                         float qscale) {
-    return op_gemm_impl(dtype, epilogue, A, W, bias, aux, aux_count, out, out_rows, ldo, M, N, K, P, T, R, qcols, qscale, 1);
-}
-
-static int op_gemm_impl(int32_t dtype, int32_t epilogue, const float* A, const float* W, const float* bias, const float* aux,
-                        int64_t aux_count, float* out, int32_t out_rows, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t P,
-                        int32_t T, int32_t R, int32_t qcols, float qscale, int allow_ksplit) {
     const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
     if (gemm_init() != hipSuccess) return -1;
     DevBuf dA, dW, dB, dX, dO;
@@ -110,7 +92,6 @@ static int op_gemm_impl(int32_t dtype, int32_t epilogue, const float* A, const f
     GemmArgs a{};
     a.A = dA.p; a.W = dW.p; a.bias = (const float*)dB.p; a.out = dO.p; a.aux = (const float*)dX.p;
     a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.P = P; a.T = T; a.R = R; a.qcols = qcols; a.qscale = qscale;
-    a.allow_ksplit = allow_ksplit;
     OP_TRY(launch_gemm(dt, (Epilogue)epilogue, a, nullptr));
     OP_TRY(hipDeviceSynchronize());
     if (f32out) OP_TRY(hipMemcpy(out, dO.p, on * 4, hipMemcpyDeviceToHost));
@@ -200,14 +181,7 @@ void fill_random_t(DType dt, void* dev, size_t n, unsigned seed, float scale) {
 }
 }  // namespace
 
-static float gemm_bench_impl(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters, int allow_ksplit);
 extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters) {
-    return gemm_bench_impl(dtype, epilogue, M, N, K, iters, 0);
-}
-extern "C" float dinov2_hip_op_gemm_bench_ksplit(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters) {
-    return gemm_bench_impl(dtype, epilogue, M, N, K, iters, 1);
-}
-static float gemm_bench_impl(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters, int allow_ksplit) {
     const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
     if (gemm_init() != hipSuccess) return -1.f;
     DevBuf dA, dW, dB, dX, dO;
@@ -227,7 +201,6 @@ static float gemm_bench_impl(int32_t dtype, int32_t epilogue, int32_t M, int32_t
     a.A = dA.p; a.W = dW.p; a.bias = (const float*)dB.p; a.out = dO.p; a.aux = (const float*)dX.p;
     a.M = M; a.N = N; a.K = K; a.ldo = epilogue == EPI_SWIGLU ? N / 2 : N; a.P = 1; a.T = 2; a.R = 0;
     a.lda = K + padA; a.ldw = K + padW;
-    a.allow_ksplit = allow_ksplit;
     a.qcols = N / 3; a.qscale = 0.125f;
     if (epilogue == EPI_PATCH) { a.P = M; a.T = M + 1; }
     hipEvent_t e0, e1;

@@ -58,15 +58,11 @@ typedef struct dinov2_hip_load_opts {
                                  receive the arena by RCCL broadcast (dinov2_hip_model_arena)                        */
     int32_t quirk_pool_const_divisor;      /* 1 (default): pooled = sum / (img_size/patch)^2  (dinov2.cpp:794,800-803) */
     int32_t quirk_pool_includes_registers; /* 1 (default): register tokens are pooled too      (dinov2.cpp:772-776)     */
-    int32_t batch_invariant; /* 1 (default, set by dinov2_hip_default_load_opts): every kernel sums K in one order -- B images == B
-                                independent forwards BIT FOR BIT, whatever the batch size, the chunking of an over-long batch or
-                                the number of devices a dinov2_hip_group shards it over.
-                                0 (opt-in low-latency mode): at small batches the two N = hidden GEMMs split their K loop -- inside
-                                the workgroup (result = acc_lo + acc_hi), and for <= 512 token rows (224 x 224, batch 1) across
-                                workgroups, with bias / LayerScale / residual applied by the LayerNorm launch that follows:
-                                reproducible run to run, but an image's last bits then depend on the size of the batch (shard,
-                                remainder chunk) it was computed in -- equal to the batched result to the stated bound only.
-                                ViT-L/14 at 224 x 224, batch 1: 1.95 -> 1.63 ms; at 518 x 518 it no longer buys anything.          */
+    int32_t batch_invariant; /* kept for ABI compatibility; the value is ignored.  EVERY plan is batch-invariant: all kernels sum K in
+                                one order, so B images == B independent forwards BIT FOR BIT, whatever the batch size, the chunking
+                                of an over-long batch or the number of devices a dinov2_hip_group shards it over.  (Round 2 / early
+                                round 3 had an opt-in mode, 0, that split K at tiny batches; the small-tile plans that replaced it are
+                                faster than it was and keep the bits: profiles/r03_small_m_gemm.md.)                              */
     int32_t reserved[9];
 } dinov2_hip_load_opts;
 

@@ -22,12 +22,6 @@ int dinov2_hip_op_gemm(int32_t dtype, int32_t epilogue, const float *A, const fl
                        const float *aux, int64_t aux_count, float *out, int32_t out_rows, int32_t ldo, int32_t M,
                        int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols, float qscale);
 
-/* dinov2_hip_op_gemm with GemmArgs.allow_ksplit = 1: few-tile, long-K shapes (M = 1 374, N = 1 024, K >= 1 024: the attn-out and
- * FFN-out GEMMs of a batch-1 forward) split K inside the workgroup (csrc/gemm.hip, KS = 2); other shapes are unaffected */
-int dinov2_hip_op_gemm_ksplit(int32_t dtype, int32_t epilogue, const float *A, const float *W, const float *bias,
-                              const float *aux, int64_t aux_count, float *out, int32_t out_rows, int32_t ldo, int32_t M,
-                              int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols, float qscale);
-
 /* fused attention over token-major qkv [B*T, 3H] (q already scaled) -> [B*T, H]; replaces dinov2.cpp:479-543 */
 int dinov2_hip_op_attention(int32_t dtype, const float *qkv, float *out, int32_t B, int32_t T, int32_t H, int32_t nh);
 
@@ -45,7 +39,6 @@ int dinov2_hip_op_probe_tr16(int16_t *out256);
 /* micro-benchmarks on device-resident uniform-random operands: average ms per launch over `iters` launches (HIP events),
  * negative on error.  Used by tools/kernel_bench.py to price one kernel against its roofline. */
 float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters);
-float dinov2_hip_op_gemm_bench_ksplit(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, int32_t iters);
 float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t H, int32_t nh, int32_t iters);
 
 /* preprocess_u8_kernel alone: raw 8-bit BGR [B, h, w, 3] -> normalised f32 BGR [B, oh, ow, 3] (mode 0 dino_preprocess,

@@ -92,9 +92,8 @@ def test_config2_vit_b_batch1_full_depth(api, pkg, ggufs):
 def test_config3_vit_l_batch32_full_depth(api, pkg, ggufs):
     """BASELINE configs[2], the benchmark's own workload: dinov2-large, all 24 layers, f16, 518x518, batch 32 -- first and last
     image of the batch against the oracle (every kernel runs its large-M plan: persistent 256-row GEMM tiles, throughput
-    attention kernel), plus the batch-1 forward of image 31: bit-identical to the batched result by default (small-M kernels, pipelined
-    attention, same summation order), and within the stated bound of it and of the oracle in the opt-in low-latency mode
-    (batch_invariant = 0: intra-workgroup split-K)."""
+    attention kernel), plus the batch-1 forward of image 31: bit-identical to the batched result (small-M kernels, pipelined
+    attention, same summation order)."""
     path = ggufs("large")
     imgs = pkg.synth.synthetic_images(32, 518, 518, seed=42)
     sess = api.Session(api.Model(path, classify=True))
@@ -113,16 +112,6 @@ def test_config3_vit_l_batch32_full_depth(api, pkg, ggufs):
     _record("config3_vit_l_b32", **rec)
     one = sess.predict(imgs[31:32], classify=True)
     assert np.array_equal(one["logits"][0], got["logits"][31]) and np.array_equal(one["patch_tokens"][0], got["patch_tokens"][31])
-    # low-latency mode: batch 1 takes the split-K plan.  One f32 rounding of difference per GEMM output is enough to flip f16 roundings
-    # downstream, and 24 layers turn flipped roundings into the same ~5e-4 every other numerics switch produces: the two plans agree
-    # to the stated bound, not to 1e-7
-    del sess
-    fast = api.Session(api.Model(path, classify=True, batch_invariant=False))
-    one = fast.predict(imgs[31:32], classify=True)
-    rec2 = {"batch1_vs_batch32_rel_dlogit": _rel(one["logits"][0], got["logits"][31])}
-    _record("config3_split_k_vs_whole", **rec2)
-    assert _rel(one["logits"][0], got["logits"][31]) <= 1e-3
-    assert _rel(one["logits"][0], ora.forward(imgs[31], classify=True)["logits"]) <= 1e-3
     np.testing.assert_allclose(got["probs"].sum(-1), 1.0, atol=1e-5)
 
 

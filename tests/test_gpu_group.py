@@ -45,10 +45,9 @@ def test_group_split_matches_single_session(api, golden_dir):
 
 
 def test_group_vit_l_shapes_equal_single_session(api, pkg, tmp_path):
-    """ViT-L/14 shapes (2 layers, K = 1 024 / 4 096: the shapes where a batch-1 forward COULD take the split-K plan), global batch
-    2 over two ranks -> every rank computes ONE image.  By default (batch_invariant = 1) the group's result equals one session's
-    batch-2 result bit for bit, i.e. it does not depend on the number of devices; a single CHW image is promoted to a batch of one
-    like Session.predict does.  With batch_invariant = 0 (opt-in) the same comparison only holds to the stated bound."""
+    """ViT-L/14 shapes (2 layers), global batch 2 over two ranks -> every rank computes ONE image with the few-tile GEMM plans.  The
+    group's result equals one session's batch-2 result bit for bit, i.e. it does not depend on the number of devices; a single CHW
+    image is promoted to a batch of one like Session.predict does."""
     path = str(tmp_path / "large2.gguf")
     pkg.synth.write_synthetic_gguf(path, "large", registers=4, num_classes=1000, seed=11, layers=2)
     imgs = pkg.synth.synthetic_images(2, 518, 518, seed=11)
@@ -62,11 +61,6 @@ def test_group_vit_l_shapes_equal_single_session(api, pkg, tmp_path):
     with pytest.raises(ValueError):
         grp.predict(np.zeros((2, 5, 518, 518), np.float32), classify=True)
     grp.close()
-    fast = api.Group(path, devices=[0, 0], classify=True, batch_invariant=False)
-    lo = fast.predict(imgs, classify=True)
-    fast.close()
-    assert not np.array_equal(lo["logits"], ref["logits"])  # the split-K plan really ran on the one-image shards
-    assert np.abs(lo["logits"] - ref["logits"]).max() <= 1e-3 * max(1.0, np.abs(ref["logits"]).max())
 
 
 def test_group_pipelined_jobs_equal_plain_predict(api, golden_dir):

@@ -434,31 +434,3 @@ def test_gemm_random_shapes_all_plans(api, seed):
     assert bad.mean() < (2e-4 if epi in (EPI_GELU, EPI_QKV) else 1e-7), f"M={M} N={N} K={K}: {bad.sum()} mismatches, first at {np.argwhere(bad)[:4]}"
 
 
-@pytest.mark.parametrize("dt", [F16, BF16])
-@pytest.mark.parametrize("M,N,K,epi", [(1374, 1024, 4096, EPI_RESID), (1374, 1024, 1024, EPI_RESID), (1374, 768, 3072, EPI_RESID),
-                                       (700, 1536, 4096, EPI_RESID), (1000, 1024, 2048, 5)])
-def test_gemm_intra_workgroup_split_k(api, dt, M, N, K, epi):
-    """GemmArgs.allow_ksplit (the plan of a batch-1 forward for attn-out / FFN-out when the model was loaded with batch_invariant = 0:
-    fewer 64 x 128 tiles than CUs, K >= 1 024):
-    two wave groups multiply the two halves of K for the same tile and group 1 hands its accumulators over through LDS.  Against
-    float64 numpy on the rounded operands; against the un-split kernel (same result to one f32 rounding of the final add, NOT bit for
-    bit -- which is why the plan is opt-IN through dinov2_hip_load_opts.batch_invariant = 0); bit-reproducible run to run."""
-    rng = np.random.default_rng(M + N + K + dt)
-    A, W = _round(rng.standard_normal((M, K)), dt), _round(rng.standard_normal((N, K)) * 0.05, dt)
-    bias, ls = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
-    x0 = rng.standard_normal((M, N)).astype(np.float32)
-
-    def run(fn):
-        out = x0.copy()
-        rc = fn(dt, epi, _p(A), _p(W), _p(bias), _p(ls) if epi == EPI_RESID else None, N if epi == EPI_RESID else 0, _p(out), M, N, M, N, K,
-                0, 0, 0, 0, 1.0)
-        assert rc == 0
-        return out
-
-    split, again, whole = run(api.lib().dinov2_hip_op_gemm_ksplit), run(api.lib().dinov2_hip_op_gemm_ksplit), run(api.lib().dinov2_hip_op_gemm)
-    prod = A.astype(np.float64) @ W.astype(np.float64).T + bias
-    ref = x0 + ls * prod if epi == EPI_RESID else prod
-    np.testing.assert_allclose(split, ref.astype(np.float32), rtol=2e-5, atol=4e-4 * np.sqrt(K / 512))
-    assert np.array_equal(split, again)
-    assert np.abs(split - whole).max() <= 1e-5 * max(1.0, np.abs(whole).max())
-    assert not np.array_equal(split, whole)  # the split plan really ran (if this ever fails the plan is no longer chosen for the shape)

@@ -22,7 +22,6 @@ ap.add_argument("--iters", type=int, default=100)
 ap.add_argument("--dtype", type=int, default=0)
 ap.add_argument("--only", default="")
 ap.add_argument("--shape", action="append", default=[], help="name,epi,M,N,K (repeatable): custom GEMM shapes")
-ap.add_argument("--ksplit", action="store_true", help="allow the intra-workgroup split-K plan (small M, long K)")
 args = ap.parse_args()
 L = api.lib()
 H, F, T, B = args.hidden, args.ffn, args.tokens, args.batch
@@ -36,7 +35,7 @@ if args.shape:
 for name, epi, m, n, k in rows:
     if args.only and name != args.only:
         continue
-    ms = (L.dinov2_hip_op_gemm_bench_ksplit if args.ksplit else L.dinov2_hip_op_gemm_bench)(args.dtype, EPI[epi], m, n, k, args.iters)
+    ms = L.dinov2_hip_op_gemm_bench(args.dtype, EPI[epi], m, n, k, args.iters)
     print(f"gemm {name:12s} M={m} N={n} K={k} epi={epi:6s} {ms:8.4f} ms  {2.0 * m * n * k / ms / 1e9:8.1f} TFLOP/s", flush=True)
 if args.shape or (args.only and args.only != "attention"):
     sys.exit(0)

@@ -23,8 +23,8 @@ for (name, regs, wtype), pub in PUBLISHED_MS.items():
     path = os.path.join(tempfile.gettempdir(), f"rt_{name}_{regs}_{wtype}.gguf")
     if not os.path.exists(path):
         pkg.synth.write_synthetic_gguf(path, name, registers=regs, num_classes=1000, seed=42, wtype=wtype)
-    def timed(batch_invariant):
-        sess = api.Session(api.Model(path, classify=True, batch_invariant=batch_invariant))
+    def timed():
+        sess = api.Session(api.Model(path, classify=True))
         for _ in range(10):
             sess.predict(img, classify=True, topk=5, want=("probs",))
         lat = []
@@ -33,11 +33,9 @@ for (name, regs, wtype), pub in PUBLISHED_MS.items():
             sess.predict(img, classify=True, topk=5, want=("probs",))
             lat.append((time.perf_counter() - t0) * 1e3)
         return lat
-    lat = timed(True)    # the library's default: batch-invariant kernels
-    lat_ll = timed(False)  # opt-in low-latency mode: K-sliced FFN-out + in-workgroup split-K for the N = hidden GEMMs
+    lat = timed()
     row = {"model": name, "registers": regs, "weights": wtype, "published_cpu_ms": pub, "mi355x_mean_ms": round(float(np.mean(lat)), 3),
-           "mi355x_p50_ms": round(float(np.median(lat)), 3), "speedup_vs_published": round(pub / float(np.mean(lat)), 1),
-           "mi355x_low_latency_mode_mean_ms": round(float(np.mean(lat_ll)), 3)}
+           "mi355x_p50_ms": round(float(np.median(lat)), 3), "speedup_vs_published": round(pub / float(np.mean(lat)), 1)}
     if args.oracle and wtype == "f16" and regs == 4 and name in ("small", "large"):
         from oracle.oracle import OracleModel
         ora = OracleModel(path)
