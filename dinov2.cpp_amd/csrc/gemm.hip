@@ -445,6 +445,7 @@ static void hipFuncSetAttribute_all() { (void)set_attr_cfg<_Float16, BM, BN, WM,
 
 hipError_t launch_gemm2(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);      // gemm2.hip, 256-row tiles
 hipError_t launch_gemm2_192(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);  // gemm2.hip, 192-row tiles
+hipError_t launch_gemm2_128(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);  // gemm2.hip, 128-row tiles, one per workgroup
 hipError_t launch_gemm2_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 hipError_t gemm2_init();
 
@@ -596,6 +597,18 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
             const double costD = (double)R + (double)a2.M * a.N / unit / 0.5 + 0.1;
             if (costC < best - 0.02) { plan = 'C'; best = costC; }
             if (costD < best - 0.02) { plan = 'D'; best = costD; }
+        }
+#ifdef DINO_GEMM_SWEEP
+        if (forced == 192) plan = 'B';
+        if (forced == 129 && !is_patch) return launch_gemm2_128(dt, epi, a, st);
+#endif
+        // F: 128-row tiles of the persistent kernel's schedule, one per workgroup, when they give 112 ... 256 workgroups: too few rows to
+        // fill the chip with 256- or 192-row tiles, enough columns that 128 x 256 tiles do (ViT-L batch 1 at 518 x 518: QKV 132 tiles
+        // 18.0 -> 15.0 us, FFN-in 176 tiles 21.1 -> 17.6; ViT-g QKV 42 -> 24; batch 4 FFN-out 64 -> 51).  Below ~112 tiles the
+        // small-tile kernel's many workgroups win, above 256 a second round starts (profiles/r03_small_m_gemm.md section 9).
+        {
+            const long t128r = (long)ntn * ((a.M + 127) / 128);
+            if (!is_patch && !forced && t128r >= 112 && t128r <= 256) return launch_gemm2_128(dt, epi, a, st);
         }
         if (is_patch) plan = (plan == 'E' || t192 < 192) ? 'E' : 'B';  // only the 192-row instantiation exists for this epilogue
         switch (plan) {

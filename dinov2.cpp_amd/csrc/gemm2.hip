@@ -45,6 +45,10 @@ __device__ unsigned long long g_gemm_prof[256 * 8];
 // dispatcher for the LAST partial round of a launch (688 tiles of 256 rows on 256 CUs are 2.69 rounds -> 3; two rounds of
 // 256-row tiles plus one round of 192-row tiles cover the same rows in 2.79).  Same schedule with a half-height second token
 // half; same K order, so a row's bits do not depend on the tile height.
+// XREP = 2 -> 128-row tiles for launches of at most ~256 of them (batch 1 at 518 x 518: QKV 132, FFN-in 176 tiles; ONE tile per
+// workgroup, no persistence): there is no second token half, so a K-tile is TWO phases -- (0,0) and (0,1) -- and three half-tile slots
+// (X0, W0, W1: 48 KiB); K-tiles rotate through a ring of three such buffers and K-tile t + 2 is staged under K-tile t, so that a
+// K-tile is still two K-tile times in flight although a K-tile takes half as long.
 template <typename T, int EPI, int XREP>
 static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem) {
     // No implicit mul+add -> fma contraction anywhere in this kernel: the unrolled epilogue instances would otherwise be
@@ -55,8 +59,10 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
     constexpr int BM = 64 * XREP, BN = 256, BK = 64;
-    constexpr int BUF = 65536;               // one K-tile: four half-tile slots of 16 KiB -- X0, X1 (token halves), W0, W1 (column halves)
-    constexpr int RX1 = 32 * (XREP - 2);     // tokens per wave-row in the second token half: 64 (256-row tiles) or 32 (192-row tiles)
+    constexpr bool ONE = XREP == 2;          // 128-row tiles: one token half, one tile per workgroup, three-buffer ring
+    constexpr int BUF = ONE ? 49152 : 65536; // one K-tile: half-tile slots of 16 KiB -- X0, X1 (token halves; 128-row tiles: X0 only), W0, W1 (column halves)
+    constexpr unsigned WOFF = ONE ? 16384u : 32768u;  // W0's slot in a buffer (W1 follows it)
+    constexpr int RX1 = 32 * (XREP - 2);     // tokens per wave-row in the second token half: 64 (256-row tiles), 32 (192-row tiles) or none
     constexpr int NI1 = RX1 / 16;            // 16-token blocks of the second half: 4 or 2
 
     int tid = threadIdx.x;
@@ -106,10 +112,11 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             for (int pc = 0; pc < 2; ++pc) {
                 const bool half8 = h == 1 && RX1 == 32;  // the 8-piece half-tile
                 if (half8 && pc == 1) continue;
+                if (h == 1 && ONE) continue;
                 const int r = (half8 ? wid : 2 * wid + pc) * 8 + (lane >> 3);
                 const int ch = (lane & 7) ^ ((r >> 1) & 7);
                 if (h < 2) {
-                    const int rx = h == 0 ? 64 : RX1;
+                    const int rx = (h == 0 || ONE) ? 64 : RX1;
                     int gm = m0 + (r / rx) * (32 * XREP) + h * 64 + (r % rx);
                     gm = gm < M ? gm : M - 1;
                     src[h][pc] = (unsigned)gm * lda2 + ch * 16;
@@ -121,7 +128,8 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     auto stage = [&](int h, int kt, int buf) {  // h is a literal at every call site
         const char* base = (h < 2 ? (const char*)p.A : (const char*)p.W) + (size_t)kt * (BK * 2);
         const bool half8 = h == 1 && RX1 == 32;
-        char* dst = smem + buf * BUF + h * 16384 + (half8 ? wid : 2 * wid) * 1024;
+        if (h == 1 && ONE) return;
+        char* dst = smem + buf * BUF + (ONE && h >= 2 ? h - 1 : h) * 16384 + (half8 ? wid : 2 * wid) * 1024;
         glds16(base + src[h][0], dst);
         if (!half8) glds16(base + src[h][1], dst + 1024);
     };
@@ -135,7 +143,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         const unsigned ch = (unsigned)(((ks * 4 + kq) ^ sw) << 4);
         xa[0][ks] = lds0 + (unsigned)((wx * 64 + fr) * 128) + ch;
         xa[1][ks] = lds0 + 16384u + (unsigned)((wx * RX1 + fr) * 128) + ch;
-        wa[ks] = lds0 + 32768u + (unsigned)((ww * 32 + fr) * 128) + ch;  // column half 1 at + 16384
+        wa[ks] = lds0 + WOFF + (unsigned)((ww * 32 + fr) * 128) + ch;  // column half 1 at + 16384
     }
 
     const int nk = K / BK;  // even (checked by the launcher): the last K-tile sits in buffer 1, where the epilogue's slices go, and
@@ -148,6 +156,11 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         stage(2, 0, 0);
         stage(1, 0, 0);
         stage(3, 0, 0);
+        if (ONE && nk > 1) {  // (the launcher gives every workgroup exactly one tile)
+            stage(0, 1, 1);
+            stage(2, 1, 1);
+            stage(3, 1, 1);
+        }
     }
     DINO_GP_INIT
     for (int tix = bidx; tix < chunkn; tix += nb_x) {
@@ -233,13 +246,43 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 
         // every wave has left the previous tile's epilogue slices (buffer 1); K-tile 0 of this tile is in flight or in buffer 0
         DINO_BAR()
-        stage(0, 1, 1);
-        stage(3, 1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but those four: K-tile 0 has landed (and the previous tile's stores)
+        if constexpr (ONE) {
+            if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // all but K-tile 1's six pieces: K-tile 0 has landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            stage(0, 1, 1);
+            stage(3, 1, 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // all but those four: K-tile 0 has landed (and the previous tile's stores)
+        }
         DINO_BAR()
         if (wx == 1) DINO_BAR()  // wave-row 1 runs one barrier behind wave-row 0
         DINO_GP(0)
 
+        if constexpr (ONE) {
+            // two phases per K-tile; K-tile t + 2 goes into the buffer K-tile t - 1 has left (last read one phase pair ago by either wave-row)
+            unsigned bo = 0;
+            int b2 = 2;
+            for (int t = 0; t < nk; ++t) {
+                const bool s2 = t + 2 < nk;
+                DINO_READ_X(0, bo)
+                DINO_READ_W(0, bo)
+                if (s2) {
+                    stage(0, t + 2, b2);
+                    stage(2, t + 2, b2);
+                }
+                DINO_PHASE_END(0, 0)
+                DINO_READ_W(1, bo)
+                if (s2) {
+                    stage(3, t + 2, b2);
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // all but K-tile t + 2: K-tile t + 1 is in LDS
+                } else if (t + 1 < nk) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                DINO_PHASE_END(0, 1)
+                bo = bo == 2u * BUF ? 0u : bo + BUF;
+                b2 = b2 == 2 ? 0 : b2 + 1;
+            }
+        } else
         for (int t = 0; t < nk; ++t) {
             const unsigned bo = (unsigned)(t & 1) * (unsigned)BUF;
             const int b1 = (t + 1) & 1, b2 = t & 1;
@@ -293,7 +336,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         int el = lane;
         asm volatile("" : "+v"(el));
         const int er = el & 15, eq = el >> 4;
-        char* const ep = smem + BUF + wid * 8192;
+        char* const ep = smem + 65536 + wid * 8192;  // (buffer 1 of the two-buffer layouts; the 128-row ring is idle by now)
         const int mbase = m0 + wx * (32 * XREP);
         const int ncol = n0 + ww * 64 + 4 * eq;  // + 32 b + 16 j: this lane's four consecutive columns of block (b, j)
 
@@ -425,6 +468,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int b = ps >> 1, q = ps & 1;
+                if (q == 1 && NI1 == 0) continue;  // 128-row tiles
                 const int nb = n0 + ww * 64 + b * 32 + (el & 7) * 4;
                 float4 add[8];
                 if constexpr (EPI == EPI_RESID || EPI == EPI_PATCH) {
@@ -520,15 +564,15 @@ static void gemm_prof_dump(const char* what, int nblocks) {
 template <typename T, int XREP>
 static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int tiles = (a.N / 256) * ((a.M + 64 * XREP - 1) / (64 * XREP));
-    const dim3 grid(tiles < 256 ? tiles : 256), block(512);
-    const size_t lds = 2 * 512 * 128;
+    const dim3 grid(XREP == 2 ? tiles : tiles < 256 ? tiles : 256), block(512);  // (128-row tiles: one tile per workgroup)
+    const size_t lds = XREP == 2 ? 3 * 49152 : 2 * 512 * 128;
 #define DINO_L2(E)                                                         \
     case E:                                                                \
         hipLaunchKernelGGL((gemm2_kernel<T, E, XREP>), grid, block, lds, st, a); \
         break;
     switch (epi) {
         case EPI_PATCH:  // the 256-row instantiation spills (the pos-embed prefetch on top of 128 accumulators); 192-row does not
-            if (XREP == 4) return hipErrorInvalidValue;
+            if (XREP != 3) return hipErrorInvalidValue;
             hipLaunchKernelGGL((gemm2_kernel<T, EPI_PATCH, 3>), grid, block, lds, st, a);
             break;
         DINO_L2(EPI_QKV)
@@ -582,11 +626,15 @@ hipError_t launch_gemm2_mixed(DType dt, Epilogue epi, const GemmArgs& a, const G
 hipError_t launch_gemm2_192(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
     return dt == DT_F16 ? launch2_t<_Float16, 3>(epi, a, st) : launch2_t<__bf16, 3>(epi, a, st);
 }
+// 128-row tiles, one per workgroup (see gemm2_body)
+hipError_t launch_gemm2_128(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    return dt == DT_F16 ? launch2_t<_Float16, 2>(epi, a, st) : launch2_t<__bf16, 2>(epi, a, st);
+}
 
 template <typename T, int XREP>
 static hipError_t attr2_t() {
     hipError_t e = hipSuccess;
-    const int lds = 2 * 512 * 128;
+    const int lds = XREP == 2 ? 3 * 49152 : 2 * 512 * 128;
 #define DINO_A2(E)                                                                  \
     if (e == hipSuccess)                                                            \
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<T, E, XREP>), \
@@ -618,6 +666,8 @@ hipError_t gemm2_init() {
     if (e == hipSuccess) e = attr2_t<__bf16, 4>();
     if (e == hipSuccess) e = attr2_t<_Float16, 3>();
     if (e == hipSuccess) e = attr2_t<__bf16, 3>();
+    if (e == hipSuccess) e = attr2_t<_Float16, 2>();
+    if (e == hipSuccess) e = attr2_t<__bf16, 2>();
     return e;
 }
 
