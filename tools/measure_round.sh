@@ -1,6 +1,6 @@
 #!/bin/bash
 # One round's measurement tier in one go (GPU box): tests, smoke, bench (+ forced single-rank RCCL run incl. the config-4 leg),
-# rocprofv3 kernel stats of the bench at batch 32 and at batch 1, HBM traffic, MFMA utilisation, the other configurations, the
+# rocprofv3 kernel stats of the bench at batch 32, at batch 1 and at batch 1 / 224 x 224, HBM traffic, MFMA utilisation, the other configurations, the
 # README table, the host-buffer path.  Usage: bash tools/measure_round.sh r03   -> gpurun_out/<tag>_measure/  (copy what should be
 # judged into profiles/<tag>_*).
 TAG=${1:-rXX}
@@ -12,6 +12,7 @@ DINOV2_BENCH_FORCE_DIST=1 timeout 900 python bench.py --steps 10 --warmup 3 --no
 import json; d=json.load(open('$O/bench_dist1_forced.json')); print('forced-dist', d['value'], d['weight_broadcast_ms'], d['broadcast_verified'], d['config4'])"
 rm -rf gpurun_out/prof_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency > $O/bench_under_rocprof.json 2> $O/prof.err; head -14 gpurun_out/prof_$TAG/p_kernel_stats.csv | cut -c1-160; cp gpurun_out/prof_$TAG/p_kernel_stats.csv $O/bench_kernel_stats.csv
 rm -rf gpurun_out/prof_b1_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency --batch 1 --steps 50 --warmup 20 > $O/bench_b1_under_rocprof.json 2> $O/prof_b1.err; cp gpurun_out/prof_b1_$TAG/p_kernel_stats.csv $O/bench_b1_kernel_stats.csv
+rm -rf gpurun_out/prof_b1s_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1s_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency --batch 1 --size 224 --steps 50 --warmup 20 > $O/bench_b1_224_under_rocprof.json 2> $O/prof_b1s.err; cp gpurun_out/prof_b1s_$TAG/p_kernel_stats.csv $O/bench_b1_224_kernel_stats.csv
 timeout 900 bash tools/hbm_traffic.sh; cp gpurun_out/hbm_traffic.json $O/
 timeout 600 bash tools/mfma_util.sh; cp gpurun_out/mfma_util.json $O/
 timeout 1800 bash tools/other_configs.sh; cp gpurun_out/bench_base_b1.json gpurun_out/bench_giant_bf16_b8.json gpurun_out/bench_large_q8_0.json gpurun_out/bench_large_q4_0.json $O/
