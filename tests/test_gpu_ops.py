@@ -332,8 +332,9 @@ def test_gemm_rows_do_not_depend_on_their_position(api, name, epi, N):
 @pytest.mark.parametrize("name,epi,N,K", [("qkv", EPI_QKV, 3072, 1024), ("gelu", EPI_GELU, 4096, 1024), ("resid", EPI_RESID, 1024, 1024),
                                           ("resid_k4096", EPI_RESID, 1024, 4096)])
 def test_gemm_small_and_large_m_agree_bit_for_bit(api, name, epi, N, K):
-    """One image (M = 1374: 64x128 tiles, 2- or 3-stage ring) against the same rows inside a batch of 32 (M = 43968: the
-    persistent 256x256 kernel): identical bits, so a token's result does not depend on the batch it arrives in."""
+    """One image (M = 1374: 128-row one-tile-per-workgroup plan for QKV / FFN-in, 64x128 few-tile plan for the N = hidden GEMMs) against
+    the same rows inside a batch of 32 (M = 43968: the persistent 256x256 kernel): identical bits, so a token's result does not depend
+    on the batch it arrives in."""
     rng = np.random.default_rng(11)
     T = 1374
     X = _round(rng.standard_normal((T, K)), F16)
@@ -345,6 +346,33 @@ def test_gemm_small_and_large_m_agree_bit_for_bit(api, name, epi, N, K):
     big = np.ascontiguousarray(np.tile(x0, (32, 1)))
     _gemm(api, F16, epi, np.ascontiguousarray(np.tile(X, (32, 1))), W, bias, aux, big, 32 * T, N, K, N, qcols=N // 3, qscale=0.125)
     assert np.array_equal(big[:T], small) and np.array_equal(big[-T:], small)
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("epi,N,K,Ms", [(EPI_QKV, 3072, 1024, (100, 261, 783, 1374, 2088, 4122, 9000)),
+                                        (EPI_RESID, 1024, 1024, (100, 261, 1374, 4122, 5496, 9000)),
+                                        (EPI_GELU, 3072, 768, (261, 1374, 2748)), (EPI_RESID, 768, 3072, (261, 1374, 4122))])
+def test_gemm_every_plan_gives_a_row_the_same_bits(api, dt, epi, N, K, Ms):
+    """launch_gemm picks a plan by shape: small tiles of 32x64, 64x64, 64x128 (few-tile plans), 64x128 / 128x128 with co-resident
+    workgroups, 128-row one-tile-per-workgroup tiles, 192- and 256-row persistent tiles and mixtures of them.  The same 100 rows put
+    through launches of 100 ... 9 000 rows (every plan at least once) must come out with the same bits every time."""
+    rng = np.random.default_rng(N + K + dt)
+    X = _round(rng.standard_normal((100, K)), dt)
+    W = _round(rng.standard_normal((N, K)) * 0.05, dt)
+    bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    x0 = rng.standard_normal((100, N)).astype(np.float32) if epi == EPI_RESID else np.zeros((100, N), np.float32)
+    ref = None
+    for M in Ms:
+        reps = (M + 99) // 100
+        A = np.ascontiguousarray(np.tile(X, (reps, 1))[:M])
+        out = np.ascontiguousarray(np.tile(x0, (reps, 1))[:M])
+        _gemm(api, dt, epi, A, W, bias, aux, out, M, N, K, N, qcols=N // 3, qscale=0.125)
+        if ref is None:
+            ref = out[:100].copy()
+            assert np.isfinite(ref).all()
+        assert np.array_equal(out[:100], ref), M
+        if M >= 200:
+            assert np.array_equal(out[M - M % 100 - 100:M - M % 100], ref), M  # the last whole copy of the rows: another tile, the same bits
 
 
 def test_gemm_swiglu_small_and_large_m_agree_bit_for_bit(api):
