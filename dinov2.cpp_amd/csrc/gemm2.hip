@@ -366,6 +366,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
             for (int sp = 0; sp < 2 * SUBP; ++sp) {
                 const int q = sp / SUBP, ih = sp % SUBP;
                 if (q == 1 && ih * IPS >= NI1) continue;  // 192-row tiles: the second token half has 32 rows
+                // GELU: the two waves of a SIMD share its VALU, the older one wins every arbitration and the younger one then runs its last
+                // third alone at half the rate.  The younger one (wave-row 1) takes priority for its first token half and gives it back for
+                // the second: FFN-in -1 % in the model (profiles/r03_gemm_notes.md section 6).  Scheduling only, no effect on the bits.
+                if (EPI == EPI_GELU && wx == 1) {
+                    if (q == 0) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
                 char* const eh = ep + (SUBP == 2 ? (sp & 1) * 4096 : 0);
 #pragma unroll
                 for (int b = 0; b < BN_; ++b)
