@@ -536,10 +536,34 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     DINO_GP_FLUSH
 }
 
+// Clock probe (bench.py's `effective_clock_ghz`): workgroup 0 of every FFN-in launch (the roofline's dominant kernel) stamps the shader
+// clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at entry and exit; the LAST launch's differences stay in
+// g_clock_probe.  shader cycles / wall time = the clock the part actually sustained under this kernel's load (it is power-limited:
+// 1.6 - 1.9 GHz of a nominal 2.4).  Four scalar loads and one store per launch.
+__device__ unsigned long long g_clock_probe[2];
+#define DINO_CLOCK_PROBE_BEGIN(EPI)                                                                                   \
+    const bool cp_on__ = ((EPI) == EPI_GELU || (EPI) == EPI_SWIGLU) && blockIdx.x == 0 && threadIdx.x == 0;           \
+    unsigned long long cp_c0__ = 0, cp_r0__ = 0;                                                                      \
+    if (cp_on__) {                                                                                                    \
+        cp_c0__ = __builtin_readcyclecounter();                                                                       \
+        cp_r0__ = __builtin_amdgcn_s_memrealtime();                                                                   \
+    }
+#define DINO_CLOCK_PROBE_END()                                                 \
+    if (cp_on__) {                                                             \
+        g_clock_probe[0] = __builtin_readcyclecounter() - cp_c0__;             \
+        g_clock_probe[1] = __builtin_amdgcn_s_memrealtime() - cp_r0__;         \
+    }
+
+hipError_t gemm_clock_probe_read(unsigned long long out[2]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 2 * sizeof(unsigned long long));
+}
+
 template <typename T, int EPI, int XREP>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DINO_CLOCK_PROBE_BEGIN(EPI)
     gemm2_body<T, EPI, XREP>(p, smem);
+    DINO_CLOCK_PROBE_END()
 }
 
 // One launch, two tile heights: every block first walks its share of the 256-row tiles of `p` (whole rounds), then its share
@@ -549,8 +573,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm2_mixed_kernel(GemmArgs p, GemmArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    DINO_CLOCK_PROBE_BEGIN(EPI)
     gemm2_body<T, EPI, 4>(p, smem);
     gemm2_body<T, EPI, 3>(q, smem);
+    DINO_CLOCK_PROBE_END()
 }
 
 #ifdef DINO_GEMM_PROF

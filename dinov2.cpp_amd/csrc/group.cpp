@@ -5,8 +5,9 @@
 // its shard offset.  No data-path collective.
 //
 // HOST BUFFERS WITHOUT A PCIe BUBBLE: each device runs `streams_per_device` (default 2) LANES -- a host thread + session
-// (stream, workspace) + input staging buffer each.  Jobs (dinov2_hip_group_submit) go to the lanes round-robin, and every
-// device works through three turnstiles in job order: host -> device copy of the shard, the forward (whole shard, one batch:
+// (stream, workspace) + input staging buffer each.  A job (dinov2_hip_group_submit) goes to the lowest lane that has no job in
+// flight -- so a caller that only ever has ONE job in flight (dinov2_hip_group_predict) stays on lane 0 and the other lanes never
+// grow a workspace -- and every device works through three turnstiles in job order: host -> device copy of the shard, the forward (whole shard, one batch:
 // splitting it would cost GEMM efficiency, measured), device -> host copy of the results.  With two jobs in flight lane B copies
 // job k + 1 in while lane A computes job k, and lane A copies job k out while lane B computes job k + 1: the GPU only ever waits
 // for the first copy-in and the last copy-out.  dinov2_hip_group_predict = submit + wait (one job in flight, nothing to overlap).
@@ -25,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -103,6 +105,7 @@ struct Job {
     bool has_out = false;
     uint32_t flags = 0;
     int remaining = 0;  // ranks that have not finished it yet
+    int lane = 0;       // the lane (of every rank) that runs it
     int rc = 0;
     char err[256] = {0};
 };
@@ -115,6 +118,7 @@ struct dinov2_hip_group {
         hipStream_t stream = nullptr;
         void* stage = nullptr;  // device copy of this lane's input images
         size_t stage_bytes = 0;
+        std::deque<int64_t> q;  // tickets assigned to this lane, in submission order (guarded by the group's mu)
         std::thread th;
     };
     struct Rank {
@@ -129,13 +133,15 @@ struct dinov2_hip_group {
     std::vector<std::unique_ptr<Rank>> ranks;
     int nlanes = 1;
     double broadcast_ms = -1.0;  // < 0: every device read the file itself
-    // job ring: job k lives in slot k % nlanes from submit until its wait returns; lane l of every rank runs the jobs k = l (mod nlanes)
+    // job ring: job k lives in slot k % nlanes from submit until its wait returns (at most nlanes jobs are in flight); the lane that runs
+    // it is chosen at submit: the lowest one without a job in flight (lane_busy)
     std::mutex mu;
     std::condition_variable cv_job, cv_done;
     int64_t submitted = 0;  // jobs handed in so far (tickets 0 .. submitted - 1)
     int64_t retired = 0;    // every ticket below this has been waited for (its slot is free)
     bool quit = false;
     std::vector<Job> ring;
+    std::vector<int> lane_busy;  // jobs in flight (submitted, not waited for) per lane
     std::mutex call_mu;  // serialises dinov2_hip_group_predict callers (submit + wait as one unit)
 };
 
@@ -216,29 +222,33 @@ void run_job(dinov2_hip_group* g, int r, int l, int64_t k, const Job& job, int* 
         if (so.topk_ids) so.topk_ids += (size_t)lo * (size_t)so.topk;
         if (so.topk_probs) so.topk_probs += (size_t)lo * (size_t)so.topk;
     }
-    // ---- turnstile 1: the forward, results left in the session's workspace
+    // ---- turnstile 1: the forward, results left in the session's workspace.  A shard longer than one pass takes (> 2^31-byte
+    // activations) is computed in passes by dinov2_hip_predict and its results must leave pass by pass, inside this turnstile: decided
+    // up front, so that the forward runs once either way.
+    const bool in_passes = (size_t)si.batch > dinov2_max_pass_batch(rk.model, h, w);
     enter(1);
-    int rc = dinov2_hip_predict(ln.session, &si, nullptr, job.flags, err, errlen);
+    int rc = dinov2_hip_predict(ln.session, &si, in_passes && job.has_out ? &so : nullptr, job.flags, err, errlen);
     if (rc == DINOV2_HIP_OK) rc = dinov2_hip_session_sync(ln.session);
-    // an over-long shard was computed in passes (> 2^31-byte activations): its results must leave pass by pass, inside this turnstile
-    const bool refetch = rc == DINOV2_HIP_OK && job.has_out && ln.session->last_b != si.batch;
-    if (refetch) rc = dinov2_hip_predict(ln.session, &si, &so, job.flags, err, errlen);
     leave(1);
     // ---- turnstile 2: device -> host, under the next job's forward on the other lane
     enter(2);
-    if (rc == DINOV2_HIP_OK && job.has_out && !refetch) rc = dinov2_hip_fetch(ln.session, &so, err, errlen);
+    if (rc == DINOV2_HIP_OK && job.has_out && !in_passes) rc = dinov2_hip_fetch(ln.session, &so, err, errlen);
     leave(2);
     *rc_out = rc;
 }
 
 void worker(dinov2_hip_group* g, int r, int l) {
     (void)hipSetDevice(g->ranks[(size_t)r]->device);
-    for (int64_t k = l;; k += g->nlanes) {
+    auto& ln = *g->ranks[(size_t)r]->lanes[(size_t)l];
+    for (;;) {
         Job job;
+        int64_t k;
         {
             std::unique_lock<std::mutex> lk(g->mu);
-            g->cv_job.wait(lk, [&] { return g->quit || g->submitted > k; });
-            if (g->quit) return;
+            g->cv_job.wait(lk, [&] { return g->quit || !ln.q.empty(); });
+            if (ln.q.empty()) return;  // (quit: free waits for the jobs in flight first, so the queues are empty by then)
+            k = ln.q.front();
+            ln.q.pop_front();
             job = g->ring[(size_t)(k % g->nlanes)];
         }
         int rc = 0;
@@ -406,6 +416,7 @@ extern "C" int dinov2_hip_group_create(const char* gguf_path, const dinov2_hip_g
     }
     g->nlanes = o.streams_per_device <= 0 ? 2 : o.streams_per_device > 4 ? 4 : o.streams_per_device;
     g->ring.resize((size_t)g->nlanes);
+    g->lane_busy.assign((size_t)g->nlanes, 0);
     for (auto& rk : g->ranks) {
         HIPG_TRY(hipSetDevice(rk->device));
         int least = 0, greatest = 0;  // numerically lower = higher priority
@@ -445,14 +456,33 @@ extern "C" int dinov2_hip_group_submit(dinov2_hip_group* g, const dinov2_hip_inp
         set_err(err, errlen, "group predict takes host buffers (each device copies its own shard)");
         return DINOV2_HIP_ERR_INVALID;
     }
+    {
+        // layout / size checks BEFORE anything is queued: turnstile 0 sizes its host -> device copy from these fields, ahead of
+        // dinov2_hip_predict's own checks
+        const int vrc = dinov2_check_input(g->ranks[0]->model, in, err, errlen);
+        if (vrc != DINOV2_HIP_OK) return vrc;
+        if ((flags & DINOV2_HIP_CLASSIFY) && !g->ranks[0]->model->hp.has_classifier) {
+            set_err(err, errlen, "classify requested but the model was loaded without a classifier head");
+            return DINOV2_HIP_ERR_NO_HEAD;
+        }
+        if (out && out->on_device == 0 && out->topk < 0) {
+            set_err(err, errlen, "negative topk");
+            return DINOV2_HIP_ERR_INVALID;
+        }
+    }
     std::unique_lock<std::mutex> lk(g->mu);
     if (g->submitted - g->retired >= g->nlanes) {
         set_err(err, errlen, "%d jobs already in flight (streams_per_device): wait for one first", g->nlanes);
         return DINOV2_HIP_ERR_INVALID;
     }
     const int64_t k = g->submitted;
+    int lane = 0;
+    while (lane < g->nlanes - 1 && g->lane_busy[(size_t)lane] != 0) ++lane;  // (fewer than nlanes in flight: a free lane exists)
     Job& slot = g->ring[(size_t)(k % g->nlanes)];
     slot = Job{};
+    slot.lane = lane;
+    ++g->lane_busy[(size_t)lane];
+    for (auto& rk : g->ranks) rk->lanes[(size_t)lane]->q.push_back(k);
     slot.in = *in;
     if (out) slot.out = *out;
     slot.has_out = out != nullptr;
@@ -476,6 +506,7 @@ extern "C" int dinov2_hip_group_wait(dinov2_hip_group* g, int64_t ticket, char* 
     g->cv_done.wait(lk, [&] { return slot.remaining == 0; });
     const int rc = slot.rc;
     if (rc != DINOV2_HIP_OK) set_err(err, errlen, "%s", slot.err);
+    --g->lane_busy[(size_t)slot.lane];
     ++g->retired;
     return rc;
 }
@@ -487,6 +518,16 @@ extern "C" int dinov2_hip_group_predict(dinov2_hip_group* g, const dinov2_hip_in
         return DINOV2_HIP_ERR_INVALID;
     }
     std::lock_guard<std::mutex> call(g->call_mu);
+    {
+        // submit + wait as one unit needs an empty pipeline: with an un-waited ticket ahead of it, the wait below would be refused
+        // ("in submission order") AFTER the job had been queued -- a ticket nobody holds, writing into the caller's buffers
+        std::lock_guard<std::mutex> lk(g->mu);
+        if (g->submitted != g->retired) {
+            set_err(err, errlen, "%lld submitted job(s) not waited for yet: dinov2_hip_group_wait them before dinov2_hip_group_predict",
+                    (long long)(g->submitted - g->retired));
+            return DINOV2_HIP_ERR_INVALID;
+        }
+    }
     int64_t t = 0;
     const int rc = dinov2_hip_group_submit(g, in, out, flags, &t, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;

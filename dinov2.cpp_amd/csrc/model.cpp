@@ -141,6 +141,31 @@ struct Dims {
 // =============================================================================================================
 // load
 // =============================================================================================================
+int dinov2_check_input(const dinov2_hip_model* m, const dinov2_hip_input* in, char* err, size_t errlen) {
+    if (!m || !in || !in->data) {
+        set_err(err, errlen, "null session / input");
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    const int ps = (int)m->hp.patch_size;
+    if (in->layout == DINOV2_HIP_U8_BGR_HWC) {  // raw images: any size, preprocessed on the device
+        if (in->batch <= 0 || in->height <= 0 || in->width <= 0) {
+            set_err(err, errlen, "raw image input must have batch, height, width >= 1");
+            return DINOV2_HIP_ERR_INVALID;
+        }
+        return DINOV2_HIP_OK;
+    }
+    if (in->layout != DINOV2_HIP_BGR_HWC && in->layout != DINOV2_HIP_RGB_CHW) {  // (raw u8 returned above)
+        set_err(err, errlen, "unknown input layout %d", in->layout);
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    if (in->batch <= 0 || in->height < ps || in->width < ps || in->height % ps || in->width % ps) {
+        set_err(err, errlen, "input must be batch >= 1 and height/width positive multiples of patch_size %d (got %d x %d x %d)",
+                ps, in->batch, in->height, in->width);
+        return DINOV2_HIP_ERR_INVALID;
+    }
+    return DINOV2_HIP_OK;
+}
+
 extern "C" void dinov2_hip_default_load_opts(dinov2_hip_load_opts* o) {
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
@@ -671,28 +696,11 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
 }
 
 int check_input(const dinov2_hip_session* s, const dinov2_hip_input* in, char* err, size_t errlen) {
-    if (!s || !in || !in->data) {
+    if (!s) {
         set_err(err, errlen, "null session / input");
         return DINOV2_HIP_ERR_INVALID;
     }
-    const int ps = (int)s->model->hp.patch_size;
-    if (in->layout == DINOV2_HIP_U8_BGR_HWC) {  // raw images: any size, preprocessed on the device
-        if (in->batch <= 0 || in->height <= 0 || in->width <= 0) {
-            set_err(err, errlen, "raw image input must have batch, height, width >= 1");
-            return DINOV2_HIP_ERR_INVALID;
-        }
-        return DINOV2_HIP_OK;
-    }
-    if (in->batch <= 0 || in->height < ps || in->width < ps || in->height % ps || in->width % ps) {
-        set_err(err, errlen, "input must be batch >= 1 and height/width positive multiples of patch_size %d (got %d x %d x %d)",
-                ps, in->batch, in->height, in->width);
-        return DINOV2_HIP_ERR_INVALID;
-    }
-    if (in->layout != DINOV2_HIP_BGR_HWC && in->layout != DINOV2_HIP_RGB_CHW) {  // (raw u8 returned above)
-        set_err(err, errlen, "unknown input layout %d", in->layout);
-        return DINOV2_HIP_ERR_INVALID;
-    }
-    return DINOV2_HIP_OK;
+    return dinov2_check_input(s->model, in, err, errlen);
 }
 
 // Opt-in (DINOV2_HIP_GRAPHS=1): second and later forwards with the same (workspace, input pointer, shape, flags) replay a
@@ -882,6 +890,17 @@ extern "C" int dinov2_hip_session_profile_read(dinov2_hip_session* s, int32_t ma
     return n;
 }
 
+size_t dinov2_max_pass_batch(const dinov2_hip_model* m, int h, int w) {
+    // The kernels address activations with 32-bit offsets (staging cursors of the GEMMs and of the attention): the widest
+    // activation buffer of one forward must stay below 2^31 bytes (ViT-L @518: 190 images per pass).
+    const Dims d1 = dims_of(m, 1, h, w);
+    const size_t widest = std::max<size_t>({3 * (size_t)m->hp.hidden_size, (size_t)m->hp.ffn_hidden, (size_t)m->kpe_pad});
+    size_t bmax = std::max<size_t>(1, ((size_t)1 << 31) / ((size_t)d1.T * widest * 2));
+    if (const char* e = getenv("DINOV2_HIP_MAX_CHUNK"))  // testing aid: force the split at small sizes
+        if (atoi(e) > 0) bmax = std::min<size_t>(bmax, (size_t)atoi(e));
+    return bmax;
+}
+
 // =============================================================================================================
 // predict
 // =============================================================================================================
@@ -900,6 +919,7 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
         return DINOV2_HIP_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m->device));
+    s->last_b = 0;  // nothing to fetch until this forward has succeeded (a failed or re-carving call must not leave the old shape behind)
     const int B = in->batch;
     int h = in->height, w = in->width, layout = in->layout;
     const bool raw_u8 = in->layout == DINOV2_HIP_U8_BGR_HWC;
@@ -911,15 +931,11 @@ extern "C" int dinov2_hip_predict(dinov2_hip_session* s, const dinov2_hip_input*
         layout = DINOV2_HIP_BGR_HWC;
     }
     {
-        // The kernels address activations with 32-bit offsets (staging cursors of the GEMMs and of the attention): the widest
-        // activation buffer of one forward must stay below 2^31 bytes.  Larger batches are split here, transparently --
-        // B images are B independent forwards, so the results do not change (ViT-L @518: 190 images per pass).  Passes run
-        // last chunk first, so the session ends up holding chunk 0 (dinov2_hip_pca3's "image 0 of the last predict").
+        // Batches longer than one pass takes (dinov2_max_pass_batch) are split here, transparently -- B images are B independent
+        // forwards, so the results do not change.  Passes run last chunk first, so the session ends up holding chunk 0
+        // (dinov2_hip_pca3's "image 0 of the last predict").
         const Dims d1 = dims_of(m, 1, h, w);
-        const size_t widest = std::max<size_t>({3 * (size_t)m->hp.hidden_size, (size_t)m->hp.ffn_hidden, (size_t)m->kpe_pad});
-        size_t bmax = std::max<size_t>(1, ((size_t)1 << 31) / ((size_t)d1.T * widest * 2));
-        if (const char* e = getenv("DINOV2_HIP_MAX_CHUNK"))  // testing aid: force the split at small sizes
-            if (atoi(e) > 0) bmax = std::min<size_t>(bmax, (size_t)atoi(e));
+        const size_t bmax = dinov2_max_pass_batch(m, h, w);
         if ((size_t)B > bmax) {
             const size_t H = m->hp.hidden_size, C = m->hp.num_classes;
             const size_t tok_rows = (size_t)(d1.T - (classify ? 1 : 1 + (int)m->hp.num_register_tokens));
@@ -1023,6 +1039,7 @@ extern "C" int dinov2_hip_debug_hidden(dinov2_hip_session* s, const dinov2_hip_i
         return DINOV2_HIP_ERR_INVALID;
     }
     HIP_TRY(hipSetDevice(m->device));
+    s->last_b = 0;  // this call overwrites the workspace: the previous predict's results are gone for dinov2_hip_fetch
     const int B = in->batch, h = in->height, w = in->width;
     rc = ensure_workspace(s, B, h, w, err, errlen);
     if (rc != DINOV2_HIP_OK) return rc;

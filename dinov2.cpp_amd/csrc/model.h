@@ -78,3 +78,10 @@ struct dinov2_hip_session {
     std::vector<double> prof_ms;
     std::vector<int> prof_n;
 };
+
+// Internal (not C-ABI) helpers shared by model.cpp and group.cpp.
+// Argument checks of dinov2_hip_predict that need no session: layout, batch, height / width against the patch size.
+int dinov2_check_input(const dinov2_hip_model* m, const dinov2_hip_input* in, char* err, size_t errlen);
+// Largest batch ONE pass of the forward takes at network input size h x w (32-bit activation offsets; DINOV2_HIP_MAX_CHUNK lowers it for
+// tests): dinov2_hip_predict cuts longer batches into passes and leaves nothing for dinov2_hip_fetch.
+size_t dinov2_max_pass_batch(const dinov2_hip_model* m, int h, int w);

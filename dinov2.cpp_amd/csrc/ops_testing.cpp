@@ -248,6 +248,15 @@ extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t
 
 namespace dinov2 { void pca_ritz(const double* yprev, const double* ynext, const double* g_parts, int nparts, int H, double* evals, double* comp); }
 // host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3, for the CPU test-suite
+// Effective shader clock under the dominant kernel: cycles and 100 MHz ticks of the last FFN-in GEMM launch (see gemm2.hip).
+extern "C" int dinov2_hip_op_clock_probe(uint64_t* cycles, uint64_t* ticks_100mhz) {
+    unsigned long long v[2] = {0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || dinov2::gemm_clock_probe_read(v) != hipSuccess) return DINOV2_HIP_ERR_HIP;
+    if (cycles) *cycles = v[0];
+    if (ticks_100mhz) *ticks_100mhz = v[1];
+    return DINOV2_HIP_OK;
+}
+
 extern "C" int dinov2_hip_op_pca_ritz(const double* yprev, const double* ynext, const double* gram, int32_t H, double* evals, double* comp) {
     if (!yprev || !ynext || !gram || !evals || H < 8) return DINOV2_HIP_ERR_INVALID;
     dinov2::pca_ritz(yprev, ynext, gram, 1, H, evals, comp);

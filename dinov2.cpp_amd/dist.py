@@ -24,22 +24,35 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
+def _via_host(dist, t) -> bool:
+    """gloo moves host memory: device tensors are staged through the host for it (bench.py's `--backend gloo` dry run of the
+    N > 1 path on a 1-GPU box, and the CPU tests); under nccl (= RCCL) device tensors go out as they are."""
+    return getattr(t, "is_cuda", False) and dist.get_backend() == "gloo"
+
+
 def broadcast_weights(dist, arena, src: int = 0, chunk_bytes: int = 1 << 30):
     """Broadcast a flat uint8 tensor in <= 1 GiB messages (ring broadcast over xGMI is per-link bound; a few large
     messages, not many small ones)."""
     n = arena.numel()
     for off in range(0, n, chunk_bytes):
-        dist.broadcast(arena[off:min(n, off + chunk_bytes)], src=src)
+        chunk = arena[off:min(n, off + chunk_bytes)]
+        if _via_host(dist, chunk):
+            host = chunk.cpu()
+            dist.broadcast(host, src=src)
+            chunk.copy_(host)
+        else:
+            dist.broadcast(chunk, src=src)
 
 
 def max_over_ranks(dist, torch, value: float, device) -> float:
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def gather_rows(dist, torch, local_rows, world: int):
     """Optional all-gather of per-rank output rows (e.g. logits [B/G, C]) into rank order."""
-    outs = [torch.empty_like(local_rows) for _ in range(world)]
-    dist.all_gather(outs, local_rows)
-    return torch.cat(outs, dim=0)
+    src = local_rows.cpu() if _via_host(dist, local_rows) else local_rows
+    outs = [torch.empty_like(src) for _ in range(world)]
+    dist.all_gather(outs, src)
+    return torch.cat(outs, dim=0).to(local_rows.device)

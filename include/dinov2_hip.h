@@ -155,7 +155,10 @@ typedef struct dinov2_hip_group_opts {
     const int32_t *devices;    /* [n_devices] HIP ordinals, or NULL for 0 .. n_devices-1                                      */
     int32_t broadcast;         /* 1: rank 0 loads, RCCL broadcast of the arena; 0: every rank loads the file                  */
     int32_t streams_per_device; /* lanes (host thread + stream + workspace) per device, 1..4; default 2 = the number of jobs
-                                   dinov2_hip_group_submit accepts before one must be waited for.  Results do not depend on it. */
+                                   dinov2_hip_group_submit accepts before one must be waited for.  Results do not depend on it.
+                                   A lane allocates its workspace (dinov2_hip_workspace_bytes of its shard) and input staging buffer
+                                   when it first runs a job; a job goes to the lowest lane with nothing in flight, so callers of
+                                   dinov2_hip_group_predict alone (one job in flight) only ever pay for lane 0.                    */
     int32_t reserved[7];
 } dinov2_hip_group_opts;
 void dinov2_hip_default_group_opts(dinov2_hip_group_opts *opts);
@@ -168,7 +171,9 @@ dinov2_hip_model *dinov2_hip_group_model(dinov2_hip_group *group, int32_t rank);
 /* wall time of the load-time arena broadcast in ms; negative when every rank read the file itself */
 double dinov2_hip_group_broadcast_ms(const dinov2_hip_group *group);
 /* dino_predict over the whole group: host input [B, ...] (any dinov2_hip_layout), host outputs [B, ...]; returns when every
- * shard has landed.  B < G leaves the high ranks idle.  One call at a time per group. */
+ * shard has landed.  B < G leaves the high ranks idle.  One call at a time per group; refused (DINOV2_HIP_ERR_INVALID, nothing
+ * queued) while a ticket of dinov2_hip_group_submit has not been waited for.  Layout / height / width are checked before
+ * anything is copied. */
 int dinov2_hip_group_predict(dinov2_hip_group *group, const dinov2_hip_input *in, dinov2_hip_output *out, uint32_t flags,
                              char *err, size_t errlen);
 /* The same call in two halves, so that ONE host thread can keep up to `streams_per_device` batches in flight: while a device

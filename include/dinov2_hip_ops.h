@@ -45,6 +45,10 @@ float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t
  * 1 dino_classify_preprocess; sizes from dinov2_hip_preprocess_size).  Replaces dinov2.cpp:106-156 on the device. */
 int dinov2_hip_op_preprocess_u8(int32_t mode, const uint8_t *bgr, int32_t B, int32_t h, int32_t w, int32_t patch, float *out);
 
+/* Shader cycles and 100 MHz wall-clock ticks that workgroup 0 of the LAST FFN-in GEMM launch (the roofline's dominant kernel) on the
+ * current device spent in the kernel: cycles / (ticks * 10 ns) = the clock the power-limited part sustained under that load. */
+int dinov2_hip_op_clock_probe(uint64_t *cycles, uint64_t *ticks_100mhz);
+
 /* host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3.  yprev [H][8] (any full-rank block), gram [8][8] = yprev^T yprev,
  * ynext [H][8] = cov * (yprev R^-1) with gram = R^T R  ->  evals [3] largest Ritz values of cov on span(yprev), comp [3][H] their
  * unit Ritz vectors, each with its largest loading positive (H >= 8) */

@@ -326,8 +326,10 @@ def test_distance_to_exact_arithmetic(api, pkg, ggufs, head_std, seed):
     with the default synthetic head and with a head scaled to trained-model logits (max|logit| ~ 13) -- this records
         |HIP - exact|, |oracle(ggml default) - exact|, |oracle(act_round = 0) - exact|, |oracle(no f16 GELU table) - exact|,
         |oracle(attention operands rounded like the MFMA path) - exact|
-    and asserts that the HIP path is no farther from exact than the WORST ggml-style mode (x 1.25 for box-to-box summation-order
-    noise).  If the f16 attention operands made the HIP path a worse approximation of the model than ggml's f32 attention, this is
+    and asserts that the HIP path is no farther from exact than the WORST ggml-style mode x 1.18 for the logits (measured 1.15 with
+    the default head, 1.00 with the trained-scale one; every kernel is deterministic, so the margin only has to cover OpenMP team
+    differences in the oracle) and x 1.10 for the patch tokens (measured 0.90 / 1.06): a regression in the attention rounding or in
+    an epilogue shows up here first.  If the f16 attention operands made the HIP path a worse approximation of the model than ggml's f32 attention, this is
     where it would show."""
     path = ggufs("large") if head_std is None else ggufs("large", head_std=head_std)
     img = pkg.synth.synthetic_images(1, 518, 518, seed=seed)
@@ -351,5 +353,5 @@ def test_distance_to_exact_arithmetic(api, pkg, ggufs, head_std, seed):
     rec["hip_tokens_over_worst_ggml_style"] = rec["hip_tokens_abs"] / worst_ggml_tok
     _record("distance_to_exact_" + ("default_head" if head_std is None else "trained_scale_head"), **rec)
     assert rec["hip_abs"] <= 1e-3 * max(1.0, big)            # the stated bound also holds against exact arithmetic
-    assert rec["hip_abs"] <= 1.25 * worst_ggml, rec          # and the HIP path is as good an approximation as a ggml-style one
-    assert rec["hip_tokens_abs"] <= 1.25 * worst_ggml_tok, rec
+    assert rec["hip_abs"] <= 1.18 * worst_ggml, rec          # and the HIP path is as good an approximation as a ggml-style one
+    assert rec["hip_tokens_abs"] <= 1.10 * worst_ggml_tok, rec

@@ -159,3 +159,139 @@ def test_group_from_cpp(tmp_path, golden_dir):
                            "-o", exe, "-L" + libdir, "-ldinov2_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     r = subprocess.run([exe, os.path.join(golden_dir, "tiny_gelu_reg4.gguf")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "GROUP_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_group_eight_entries_vit_l_shapes(api, pkg, tmp_path):
+    """The shape of the 8-GPU node on the one GPU there is: an 8-entry device list (all device 0) at ViT-L/14 widths (2 layers),
+    global batches 13 (B % G != 0: shards of 2 and 1 images), 3 (B < G: five entries idle) and 8, with TWO jobs in flight.  Every
+    output equals one session's result bit for bit, whatever the number of entries."""
+    path = str(tmp_path / "large2.gguf")
+    pkg.synth.write_synthetic_gguf(path, "large", registers=4, num_classes=1000, seed=13, layers=2)
+    imgs = pkg.synth.synthetic_images(13, 224, 224, seed=13)
+    sess = api.Session(api.Model(path, classify=True))
+    ref = sess.predict(imgs, classify=True, topk=5)
+    grp = api.Group(path, devices=[0] * 8, classify=True)
+    assert grp.size == 8
+    got = grp.predict(imgs, classify=True, topk=5)
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    # two jobs in flight: B = 3 behind B = 13, then B = 8 behind B = 3
+    h13 = grp.submit(imgs, classify=True)
+    h3 = grp.submit(imgs[5:8], classify=False)
+    o13 = grp.wait(h13)
+    h8 = grp.submit(imgs[2:10], classify=True)
+    o3 = grp.wait(h3)
+    o8 = grp.wait(h8)
+    assert np.array_equal(o13["logits"], ref["logits"])
+    f3 = sess.predict(imgs[5:8], classify=False)
+    for k in f3:
+        assert np.array_equal(o3[k], f3[k]), k
+    assert np.array_equal(o8["logits"], ref["logits"][2:10]) and np.array_equal(o8["patch_tokens"], ref["patch_tokens"][2:10])
+    grp.close()
+
+
+def test_group_predict_refused_while_a_ticket_is_pending(api, golden_dir):
+    """dinov2_hip_group_predict = submit + wait as one unit: with an un-waited ticket ahead of it the call is refused BEFORE anything is
+    queued (round 3: the job was queued, its wait refused, and the orphan wrote into the caller's buffers after the error return).
+    The pending ticket stays waitable and the group usable."""
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    grp = api.Group(gguf, devices=[0, 0], classify=True)
+    imgs = np.random.default_rng(21).standard_normal((5, 3, 56, 84)).astype(np.float32)
+    ref = sess.predict(imgs, classify=True)
+    h = grp.submit(imgs, classify=True)
+    with pytest.raises(api.DinoError) as e:
+        grp.predict(imgs[:2], classify=True)
+    assert e.value.status == 4 and "not waited" in str(e.value)
+    assert np.array_equal(grp.wait(h)["logits"], ref["logits"])
+    assert np.array_equal(grp.predict(imgs[:2], classify=True)["logits"], ref["logits"][:2])
+    grp.close()
+
+
+def test_group_rejects_bad_descriptors_before_copying(api, golden_dir):
+    """Layout / height / width are validated in dinov2_hip_group_submit, before turnstile 0 sizes a host -> device copy from them: an
+    unknown layout, a size that is not a multiple of the patch size and a zero batch come back as INVALID with nothing queued (the
+    next call runs as ticket 0 would)."""
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    grp = api.Group(gguf, devices=[0, 0], classify=True)
+    L = api.lib()
+    buf = np.zeros((2, 3, 56, 84), np.float32)
+    err = C.create_string_buffer(256)
+    t = C.c_int64(-1)
+    for layout, hh, ww, b in ((7, 56, 84, 2), (api.RGB_CHW, 57, 84, 2), (api.RGB_CHW, 56, 84, 0), (api.RGB_CHW, 1 << 20, 84, 2)):
+        if (hh, ww, b) == (1 << 20, 84, 2):
+            hh = (1 << 20) + 1  # not a multiple of 14: rejected before any size arithmetic is trusted
+        i = api.Input(buf.ctypes.data, b, hh, ww, layout, 0)
+        assert L.dinov2_hip_group_submit(grp._h, C.byref(i), None, api.CLASSIFY, C.byref(t), err, len(err)) == 4, (layout, hh, ww, b)
+        assert t.value == -1
+    ref = api.Session(api.Model(gguf, classify=True)).predict(buf, classify=True)
+    assert np.array_equal(grp.predict(buf, classify=True)["logits"], ref["logits"])
+    grp.close()
+
+
+def test_group_shard_cut_into_passes(api, golden_dir, monkeypatch):
+    """A shard longer than one pass of the forward takes (forced here with DINOV2_HIP_MAX_CHUNK = 2) goes through the group with ONE
+    chunked predict inside the forward turnstile, results leaving pass by pass; same bits as the un-chunked single session, for one
+    and for two jobs in flight."""
+    gguf = os.path.join(golden_dir, "tiny_swiglu_reg4.gguf")
+    imgs = np.random.default_rng(31).standard_normal((11, 3, 70, 84)).astype(np.float32)
+    ref = api.Session(api.Model(gguf, classify=True)).predict(imgs, classify=True, topk=2)
+    grp = api.Group(gguf, devices=[0, 0], classify=True)
+    monkeypatch.setenv("DINOV2_HIP_MAX_CHUNK", "2")  # shards of 6 and 5 images -> 3 passes each
+    got = grp.predict(imgs, classify=True, topk=2)
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    h1 = grp.submit(imgs, classify=True)
+    h2 = grp.submit(imgs[:3], classify=True)  # 2 + 1 images: the first entry's shard is exactly one pass
+    assert np.array_equal(grp.wait(h1)["patch_tokens"], ref["patch_tokens"])
+    assert np.array_equal(grp.wait(h2)["logits"], ref["logits"][:3])
+    monkeypatch.delenv("DINOV2_HIP_MAX_CHUNK")
+    assert np.array_equal(grp.predict(imgs, classify=True)["logits"], ref["logits"])
+    grp.close()
+
+
+def test_group_predict_only_callers_stay_on_one_lane(api, pkg, tmp_path):
+    """With the default two lanes per device a caller that only uses the blocking dinov2_hip_group_predict has one job in flight: it
+    must keep running on lane 0, so that the second lane never allocates a workspace (round 3 alternated lanes by ticket parity and
+    doubled the device memory of every predict-only user).  Device memory in use after a few calls: two-lane group == one-lane group."""
+    import torch
+    path = str(tmp_path / "large2.gguf")
+    pkg.synth.write_synthetic_gguf(path, "large", registers=4, num_classes=1000, seed=5, layers=2)
+    imgs = pkg.synth.synthetic_images(4, 518, 518, seed=5)
+
+    def used_after(lanes):
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        grp = api.Group(path, devices=[0], classify=True, streams_per_device=lanes, broadcast=False)
+        for _ in range(4):
+            out = grp.predict(imgs, classify=True)
+        free1, _ = torch.cuda.mem_get_info()
+        grp.close()
+        return free0 - free1, out
+
+    one, o1 = used_after(1)
+    two, o2 = used_after(2)
+    assert np.array_equal(o1["logits"], o2["logits"])
+    ws = api.Model(path, classify=True).workspace_bytes(4, 518, 518)
+    assert ws > 64 << 20  # the workspace is what would be doubled: large enough to stand out
+    assert two < one + ws // 2, (one, two, ws)
+
+
+def test_fetch_refused_after_the_workspace_was_overwritten(api, golden_dir):
+    """dinov2_hip_fetch copies out the LAST predict: dinov2_hip_debug_hidden overwrites the workspace and a failed predict may have
+    re-carved it -- after either, fetch must say INVALID instead of returning rows of whatever is there now."""
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    sess = api.Session(api.Model(gguf, classify=True))
+    imgs = np.random.default_rng(9).standard_normal((2, 3, 56, 84)).astype(np.float32)
+    L = api.lib()
+    err = C.create_string_buffer(256)
+    out, o = api._alloc_outputs(sess.model.hparams, 2, 56, 84, api.RGB_CHW, True, 0, ("cls", "patch_tokens", "logits", "probs"))
+    i = api.Input(imgs.ctypes.data, 2, 56, 84, api.RGB_CHW, 0)
+    assert L.dinov2_hip_predict(sess._h, C.byref(i), None, api.CLASSIFY, err, len(err)) == 0
+    assert L.dinov2_hip_fetch(sess._h, C.byref(o), err, len(err)) == 0
+    sess.debug_hidden(imgs, 1)
+    assert L.dinov2_hip_fetch(sess._h, C.byref(o), err, len(err)) == 4
+    assert L.dinov2_hip_predict(sess._h, C.byref(i), None, api.CLASSIFY, err, len(err)) == 0
+    bad = api.Input(0, 2, 56, 84, api.RGB_CHW, 0)  # null data: fails in the argument checks, before anything ran
+    assert L.dinov2_hip_predict(sess._h, C.byref(bad), None, api.CLASSIFY, err, len(err)) == 4
+    assert L.dinov2_hip_fetch(sess._h, C.byref(o), err, len(err)) == 0  # the workspace was not touched: the last forward is still there
