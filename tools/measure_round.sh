@@ -19,4 +19,4 @@ timeout 1800 bash tools/other_configs.sh; cp gpurun_out/bench_base_b1.json gpuru
 timeout 600 python bench.py --model small --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_small_b32.json 2> $O/bench_small.err
 timeout 900 python tools/readme_table.py > $O/readme_table.log 2>&1; tail -12 $O/readme_table.log; cp gpurun_out/readme_table.json $O/ 2>/dev/null
 timeout 600 python tools/host_path.py > $O/host_path.log 2>&1; tail -12 $O/host_path.log; cp gpurun_out/host_path.json $O/
-cp gpurun_out/parity_r03.json $O/parity.json 2>/dev/null
+cp gpurun_out/parity_r04.json $O/parity.json 2>/dev/null
