@@ -540,7 +540,7 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 // clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at entry and exit; the LAST launch's differences stay in
 // g_clock_probe.  shader cycles / wall time = the clock the part actually sustained under this kernel's load (it is power-limited:
 // 1.6 - 1.9 GHz of a nominal 2.4).  Four scalar loads and one store per launch.
-__device__ unsigned long long g_clock_probe[2];
+__device__ unsigned long long g_clock_probe[3];  // cycles, 100 MHz ticks, 100 MHz stamp at the end
 #define DINO_CLOCK_PROBE_BEGIN(EPI)                                                                                   \
     const bool cp_on__ = ((EPI) == EPI_GELU || (EPI) == EPI_SWIGLU) && blockIdx.x == 0 && threadIdx.x == 0;           \
     unsigned long long cp_c0__ = 0, cp_r0__ = 0;                                                                      \
@@ -550,12 +550,14 @@ __device__ unsigned long long g_clock_probe[2];
     }
 #define DINO_CLOCK_PROBE_END()                                                 \
     if (cp_on__) {                                                             \
+        const unsigned long long r1__ = __builtin_amdgcn_s_memrealtime();      \
         g_clock_probe[0] = __builtin_readcyclecounter() - cp_c0__;             \
-        g_clock_probe[1] = __builtin_amdgcn_s_memrealtime() - cp_r0__;         \
+        g_clock_probe[1] = r1__ - cp_r0__;                                     \
+        g_clock_probe[2] = r1__;                                               \
     }
 
-hipError_t gemm_clock_probe_read(unsigned long long out[2]) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 2 * sizeof(unsigned long long));
+hipError_t gemm_clock_probe_read(unsigned long long out[3]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 3 * sizeof(unsigned long long));
 }
 
 template <typename T, int EPI, int XREP>

@@ -1,0 +1,557 @@
+// gemm4.hip -- fourth generation of the f16/bf16 MFMA GEMM: the 256 x 256 x 64 tile on FOUR waves (one per SIMD, 512 registers each: 256
+// accumulators in AGPRs + fragments in VGPRs), every wave a 128 x 128 output block, the K loop ONE hand-ordered instruction stream per
+// wave.  Same contract, epilogues, K order (a row's bits are those of gemm.hip / gemm2.hip) and XCD-aware persistent tile walk as
+// gemm2.hip, which stays for the shapes this kernel does not take (K / 64 < 4, the patch-embed epilogue, 128-row one-tile-per-workgroup
+// launches).
+//
+// Why (profiles/r04_gemm4w.md): gemm2.hip's K loop runs barrier-separated MEM / MMA sections shared by the two waves of a SIMD and
+// reaches ~75 % matrix-pipe duty; the vendor's assembly kernel of the same macro tile is a single wave per SIMD issuing its 128 MFMAs per
+// K-tile back to back with the memory instructions in their shadow.  Rebuilt here from scratch (standalone probe:
+// tools/probes/gemm4w.hip, where the schedule was measured): 88 % duty in the K loop -- at which point the part's power limit, not
+// the schedule, sets the rate (the shader clock drops from 1.87 to 1.66 GHz; duty x clock moves + 3 %) -- no tile prologue (the next
+// tile's first two K-tiles are staged under the last two of the current one and its first fragments are in registers before the
+// epilogue starts), and an epilogue that no second wave of the SIMD competes with.
+//
+//   LDS (160 KiB): X buffers 0 / 1 at 0 / 32 KiB, W buffers 0 / 1 at 64 / 96 KiB (a buffer = 256 rows x 128 B, one K-tile of one operand,
+//   16-byte chunks XOR-swizzled by (row >> 1) & 7 on the SOURCE side of the LDS-DMA and on the fragment reads); 4 x 8 KiB epilogue slices at
+//   128 KiB.
+//   Wave (wr, wc) = (wid >> 1, wid & 1): tokens [16 NI wr, + 16 NI) x columns [128 wc, + 128), NI x 8 blocks of 16 x 16 (NI = 8: 256-row
+//   tiles, 6: 192-row tiles for the partial last round, same launch -- gemm4_mixed_kernel), acc[i][j] in AGPRs; OPERAND SWAP as in
+//   gemm2.hip (weight fragment = MFMA A operand): a lane owns one token and four consecutive output columns.
+//   Fragment registers: P = k-step 0 of a K-tile (NI X + 8 W fragments of 4 VGPRs), Q = k-step 1.  MFMA order: column block j outer,
+//   token block i inner; MFMA index m = 64 ks + 8 j + i.
+//   K-tile t in buffer b = t & 1:
+//     m = 0, 2 .. 30   one ds_read_b128 of Q(t) behind every second MFMA (W fragments first)
+//     m = 8 k          one LDS-DMA piece (global_load_lds_dwordx4, 8 rows x 128 B) per 8 MFMAs: before barrier A the LAST pieces of K-tile
+//                      t + 1 (-> buffer b ^ 1), after it the FIRST pieces of K-tile t + 2 (-> buffer b): the staging of a K-tile spans one
+//                      whole K-tile time, and every piece has >= 1 000 matrix-pipe cycles to land
+//     m = 39           s_waitcnt lgkmcnt(0); s_barrier      [A] every wave has read all of buffer b
+//     m = 103          s_waitcnt vmcnt(8); s_barrier        [B] K-tile t + 1 is in buffer b ^ 1 for everyone (8 = pieces issued since A)
+//     m = 104 .. 119   one ds_read_b128 of P(t + 1) per MFMA; s_waitcnt lgkmcnt(0) at the end
+//   Hazards (MI355X_MICROARCH.md, "Two waves per SIMD" item 7): LDS-DMA data is read only after the issuing waves' counted vmcnt AND a
+//   barrier [B]; a buffer is re-staged only after an lgkmcnt(0) + barrier [A] behind its last read.
+#include <cstdio>
+#include <type_traits>
+#include <utility>
+
+#include "device_types.h"
+#include "kernels.h"
+
+namespace dinov2 {
+
+template <int... Is, class F>
+static __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+static __device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
+
+// The K loop's instructions, as asm statements: volatile statements keep their program order, so the stream below is emitted exactly as
+// written; hipcc only allocates the registers ("a": accumulator file).  Nothing else in this kernel uses M0 (the LDS-DMA destination),
+// which is written in the same statement that reads it.
+#define DINO4_MFMA_F16(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(ACC) : "v"(W), "v"(X))
+#define DINO4_MFMA_F16_Z(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=a"(ACC) : "v"(W), "v"(X))
+#define DINO4_MFMA_BF16(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(W), "v"(X))
+#define DINO4_MFMA_BF16_Z(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(W), "v"(X))
+#define DINO4_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+// (M0 = one wave-uniform base + an immediate: sixteen pieces x two buffers would otherwise sit in thirty-two SGPRs)
+#define DINO4_GLDS(VOFF, SBASE, LDSBASE, IMM)                                                                                   \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(LDSBASE), "n"(IMM) \
+                 : "memory", "scc")
+
+// Clock probe (bench.py's `effective_clock_ghz`; see gemm2.hip): [0] shader cycles, [1] 100 MHz ticks of workgroup 0 of the last FFN-in
+// launch of THIS file's kernels, [2] the 100 MHz stamp at its end (the reader takes the later of this and gemm2.hip's).
+__device__ unsigned long long g_clock_probe4[3];
+hipError_t gemm4_clock_probe_read(unsigned long long out[3]) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe4), 3 * sizeof(unsigned long long));
+}
+
+constexpr int G4_PA = 39, G4_PB = 103;  // barrier A / B behind these MFMA indices
+constexpr int G4_NPRE = G4_PA / 8 + 1;  // staging slots (m = 8 k) up to barrier A: 5
+constexpr int G4_NB = (G4_PB - 8 * G4_NPRE) / 8 + 1;  // slots between the barriers: 8
+
+template <typename T, int EPI, int NI>
+static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem) {
+    // (no implicit mul+add -> fma contraction: an element's bits must not depend on where its row sits in a tile -- see gemm2.hip)
+#pragma clang fp contract(off)
+    using E = Elem<T>;
+    using vec4 = typename E::vec4;
+    constexpr bool F16 = std::is_same<T, _Float16>::value;
+    constexpr int BM = 32 * NI, BN = 256;
+    constexpr int NI1 = NI - 4;        // 16-token blocks of a wave's second token half: 4 or 2
+    constexpr int NP = NI + 8;         // LDS-DMA pieces per wave and K-tile: NI of X, 8 of W
+    constexpr int NPOST = 16 - G4_NPRE;  // slots behind barrier A: pieces 0 .. min(NP, NPOST) - 1 of the K-tile two ahead
+    static_assert(NP <= 16 && G4_NB <= NPOST && NP > NPOST, "staging schedule");
+
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));  // opaque: nothing lane-derived is shared between the two bodies of gemm4_mixed_kernel
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1;
+    const int M = p.M, N = p.N, K = p.K;
+    const unsigned lda2 = (unsigned)(p.lda ? p.lda : K) * 2u, ldw2 = (unsigned)(p.ldw ? p.ldw : K) * 2u;
+    const int ntn = N / BN, ntm = (M + BM - 1) / BM;
+    const int ntiles = ntn * ntm;
+    const int nk = K / 64;  // even, >= 4 (checked by the launcher)
+
+    // XCD-aware persistent tile walk (gemm2.hip): block b sits on XCD b % 8, every XCD walks a contiguous chunk of the tile order in
+    // patches of GM row panels x 32 / GM column tiles
+    const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+    const int nb_x = ((int)gridDim.x >> 3) + (xcd < ((int)gridDim.x & 7) ? 1 : 0);
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int chunk0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int chunkn = tq + (xcd < tr ? 1 : 0);
+    constexpr int GM = 8;
+    auto tile_mn = [&](int lid, int& m0, int& n0) {
+        const int g = lid / (GM * ntn), r = lid - g * (GM * ntn);
+        const int gm = ntm - g * GM < GM ? ntm - g * GM : GM;
+        const int n = r / gm, mi = r - n * gm;
+        m0 = (g * GM + mi) * BM;
+        n0 = n * BN;
+    };
+
+    // ---- staging.  Piece pc of a wave (0 .. NP - 1): X and W alternate while X has pieces left (pc < 2 NI: operand pc & 1, row block
+    // pc >> 1), then W only (row block pc - NI).  Wave w moves X rows [8 NI w, + 8 NI) and W rows [64 w, + 64) of the tile; a piece is 8
+    // rows x 128 B (lane -> row lane >> 3, 16-byte chunk lane & 7, XOR-swizzled on the source side); X rows are clamped to M.
+    unsigned so[NP];  // byte offsets from p.A / p.W of this lane's 16 bytes of every piece (K-tile 0; + 128 kt through the scalar base)
+    auto piece_off = [&](int pc, int m0, int n0) -> unsigned {
+        const bool isw = pc >= 2 * NI || (pc & 1);
+        const int rb = pc >= 2 * NI ? pc - NI : pc >> 1;
+        const int r = (isw ? 64 : 8 * NI) * wid + 8 * rb + (lane >> 3);
+        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        if (isw) return (unsigned)(n0 + r) * ldw2 + ch * 16;
+        int gm = m0 + r;
+        gm = gm < M ? gm : M - 1;
+        return (unsigned)gm * lda2 + ch * 16;
+    };
+    const unsigned lds0 = (unsigned)(uintptr_t)(DINO_LDS_AS char*)smem;
+    const unsigned ldsx = lds0 + (unsigned)wid * (NI * 1024u), ldsw = lds0 + 65536u + (unsigned)wid * 8192u;
+
+    // ---- fragment addresses: lane -> row lane & 15 of a 16-row block, 16-byte chunk (4 ks + (lane >> 4)) ^ ((row >> 1) & 7)
+    const int fr = lane & 15, kq = lane >> 4, sw = (fr >> 1) & 7;
+    unsigned xa[2], wa[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const unsigned ch = (unsigned)(((ks * 4 + kq) ^ sw) << 4);
+        xa[ks] = lds0 + (unsigned)((wr * (16 * NI) + fr) * 128) + ch;
+        wa[ks] = lds0 + 65536u + (unsigned)((wc * 128 + fr) * 128) + ch;
+    }
+
+    // acc[i][j][e] = C[m0 + 16 NI wr + 16 i + (lane & 15)][n0 + 128 wc + 16 j + 4 (lane >> 4) + e]
+    f32x4 acc[NI][8];
+    u32x4 Px[NI], Pw[8], Qx[NI], Qw[8];
+
+    const char* const Ab = (const char*)p.A;
+    const char* const Wb = (const char*)p.W;
+
+#define DINO4_PIECE(PC, KT, BUF)                                                                                            \
+    {                                                                                                                       \
+        constexpr int pc__ = (PC);                                                                                          \
+        constexpr bool isw__ = pc__ >= 2 * NI || (pc__ & 1);                                                                \
+        constexpr int rb__ = pc__ >= 2 * NI ? pc__ - NI : pc__ >> 1;                                                        \
+        if constexpr (isw__) DINO4_GLDS(so[pc__], Wb + (size_t)(KT) * 128, ldsw, (BUF) * 32768 + rb__ * 1024);              \
+        else DINO4_GLDS(so[pc__], Ab + (size_t)(KT) * 128, ldsx, (BUF) * 32768 + rb__ * 1024);                               \
+    }
+
+    // One K-tile in buffer B.  FIRST: the accumulators start from zero (first K-tile of an output tile).  Staging under it: the slots up
+    // to barrier A carry the last NP - NPOST pieces of the K-tile that goes into buffer b ^ 1 (kt_pre; if pre_on); at A `at_a()` runs
+    // (it switches the piece offsets to the next output tile where the staging crosses over); the slots behind A carry the first NPOST
+    // pieces of the K-tile that goes into THIS buffer (kt_post; if post_on).  do_readp: read P of the next K-tile behind barrier B.
+    auto ktile = [&acc, &Px, &Pw, &Qx, &Qw, &xa, &wa, &so, &ldsx, &ldsw, Ab, Wb](auto bc, auto firstc, int kt_pre, bool pre_on, auto&& at_a,
+                                                                                int kt_post, bool post_on, bool do_readp) {
+        static_for<128>([&acc, &Px, &Pw, &Qx, &Qw, &xa, &wa, &so, &ldsx, &ldsw, Ab, Wb, &kt_pre, &pre_on, &at_a, &kt_post, &post_on, &do_readp,
+                         bc, firstc](auto mc) {
+            constexpr int m = decltype(mc)::value;
+            constexpr int b = decltype(bc)::value;
+            constexpr bool FIRST = decltype(firstc)::value;
+            constexpr int ks = m >> 6, j = (m >> 3) & 7, i = m & 7;
+            if constexpr (i < NI) {
+                if constexpr (ks == 0) {
+                    if constexpr (FIRST) {
+                        if constexpr (F16) DINO4_MFMA_F16_Z(acc[i][j], Pw[j], Px[i]);
+                        else DINO4_MFMA_BF16_Z(acc[i][j], Pw[j], Px[i]);
+                    } else {
+                        if constexpr (F16) DINO4_MFMA_F16(acc[i][j], Pw[j], Px[i]);
+                        else DINO4_MFMA_BF16(acc[i][j], Pw[j], Px[i]);
+                    }
+                } else {
+                    if constexpr (F16) DINO4_MFMA_F16(acc[i][j], Qw[j], Qx[i]);
+                    else DINO4_MFMA_BF16(acc[i][j], Qw[j], Qx[i]);
+                }
+            }
+            // Q(t): k-step 1 of this K-tile (W fragments first: their registers have been free longest)
+            if constexpr (m % 2 == 0 && m / 2 < 8 + NI) {
+                constexpr int q = m / 2;
+                if constexpr (q < 8) DINO4_DSR(Qw[q], wa[1], q * 2048 + b * 32768);
+                else DINO4_DSR(Qx[q - 8], xa[1], (q - 8) * 2048 + b * 32768);
+            }
+            // staging slots
+            if constexpr (m % 8 == 0) {
+                constexpr int k = m / 8;
+                if constexpr (k < G4_NPRE) {
+                    if constexpr (NPOST + k < NP) {
+                        if (pre_on) DINO4_PIECE(NPOST + k, kt_pre, b ^ 1)
+                    }
+                } else {
+                    if (post_on) DINO4_PIECE(k - G4_NPRE, kt_post, b)
+                }
+            }
+            if constexpr (m == G4_PA) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+                at_a();
+            }
+            if constexpr (m == G4_PB) {
+                if (post_on) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G4_NB) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                asm volatile("s_barrier" ::: "memory");
+            }
+            // P(t + 1): k-step 0 of the next K-tile, from the other buffer
+            if constexpr (m > G4_PB && m <= G4_PB + 8 + NI) {
+                constexpr int q = m - G4_PB - 1;
+                if (do_readp) {
+                    if constexpr (q < 8) DINO4_DSR(Pw[q], wa[0], q * 2048 + (b ^ 1) * 32768);
+                    else DINO4_DSR(Px[q - 8], xa[0], (q - 8) * 2048 + (b ^ 1) * 32768);
+                }
+            }
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    static_assert(2 * (8 + 8) - 2 < G4_PA && G4_PB + 16 <= 127, "fragment reads fit their windows");
+
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using TT = std::integral_constant<bool, true>;
+    using TF = std::integral_constant<bool, false>;
+    auto nop = [] {};
+
+    if (bidx < chunkn) {
+        int pm0, pn0;
+        tile_mn(chunk0 + bidx, pm0, pn0);
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) so[pc] = piece_off(pc, pm0, pn0);
+        // every wave has left the previous body's epilogue slices and buffers (gemm4_mixed_kernel runs two bodies back to back)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // K-tile 0 whole, K-tile 1's first NPOST pieces (its last ones go out before barrier A of K-tile 0, like everywhere else)
+        static_for<NP>([&so, &ldsx, &ldsw, Ab, Wb](auto pcc) { DINO4_PIECE(decltype(pcc)::value, 0, 0) });
+        static_for<NPOST>([&so, &ldsx, &ldsw, Ab, Wb](auto pcc) { DINO4_PIECE(decltype(pcc)::value, 1, 1) });
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPOST) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        static_for<8 + NI>([&Px, &Pw, &xa, &wa](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if constexpr (q < 8) DINO4_DSR(Pw[q], wa[0], q * 2048);
+            else DINO4_DSR(Px[q - 8], xa[0], (q - 8) * 2048);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    for (int tix = bidx; tix < chunkn; tix += nb_x) {
+        int m0, n0;
+        tile_mn(chunk0 + tix, m0, n0);
+        const bool has_next = tix + nb_x < chunkn;
+
+        // K-tiles 0, 1 (accumulators from zero), the middle, and the last two, under which the staging crosses over to the next output tile
+        ktile(T0{}, TT{}, 1, true, nop, 2, true, true);
+        ktile(T1{}, TF{}, 2, true, nop, 3, true, true);
+        for (int t = 2; t < nk - 2; t += 2) {
+            ktile(T0{}, TF{}, t + 1, true, nop, t + 2, true, true);
+            ktile(T1{}, TF{}, t + 2, true, nop, t + 3, true, true);
+        }
+        int nm0 = 0, nn0 = 0;
+        if (has_next) tile_mn(chunk0 + tix + nb_x, nm0, nn0);
+        ktile(T0{}, TF{}, nk - 1, true,
+              [&] {
+                  if (has_next) {
+#pragma unroll
+                      for (int pc = 0; pc < NP; ++pc) so[pc] = piece_off(pc, nm0, nn0);
+                  }
+              },
+              0, has_next, true);
+        ktile(T1{}, TF{}, 0, has_next, nop, 1, has_next, has_next);
+
+        // ---- epilogue (gemm2.hip's, per 64-column group cg of the wave's 128 columns): each wave transposes its result through a private
+        // 8 KiB LDS slice and moves whole 128-byte lines.  Slice image: 64 rows x 128 B, 16-byte slot s of row r stored at s ^ (r & 7).
+        // `el` launders the lane id: without it LICM hoists the loop-invariant epilogue addresses out of the persistent tile loop and
+        // they stay live across the K loop.
+        int el = lane;
+        asm volatile("" : "+v"(el));
+        const int er = el & 15, eq = el >> 4;
+        char* const ep = smem + 131072 + wid * 8192;
+        const int mbase = m0 + wr * (16 * NI);
+#define DINO4_ACC(Q_, B_, I_, J_) acc[((Q_)*4 + (I_)) < NI ? ((Q_)*4 + (I_)) : 0][cg * 4 + (B_)*2 + (J_)]  /* (the clamp only ever acts in dead code) */
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const int nw0 = n0 + wc * 128 + cg * 64;  // first column of this 64-column group
+            const int ncol = nw0 + 4 * eq;            // + 32 b + 16 j: this lane's four consecutive columns of block (b, j)
+            float4 bs[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    bs[b][j] = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+            if constexpr (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_SWIGLU) {
+                // 2-byte outputs: two passes (token halves) of 64 rows x 64 columns (SwiGLU: x 32)
+                const float qs = (EPI == EPI_QKV && nw0 < p.qcols) ? p.qscale : 1.0f;
+                constexpr int BN_ = EPI == EPI_SWIGLU ? 1 : 2;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+#pragma unroll
+                    for (int b = 0; b < BN_; ++b)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const float bb[4] = {bs[b][j].x, bs[b][j].y, bs[b][j].z, bs[b][j].w};
+                            const float b2[4] = {bs[1][j].x, bs[1][j].y, bs[1][j].z, bs[1][j].w};
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                if (q == 1 && i >= NI1) continue;  // 192-row tiles: the second pass has 32 rows
+                                vec4 o;
+                                if constexpr (EPI == EPI_GELU) {
+                                    // ggml semantics: y = table[f16(x)], table[h] = f16(gelu_tanh(f32(h))); two columns per instruction
+                                    // (v_pk_*_f32: IEEE results identical to the scalar ops of gemm.hip, so the kernels agree bit for bit)
+                                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                                    for (int e2 = 0; e2 < 2; ++e2) {
+                                        f32x2 v = {DINO4_ACC(q, b, i, j)[2 * e2], DINO4_ACC(q, b, i, j)[2 * e2 + 1]};
+                                        v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
+                                        asm("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
+                                        typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+                                        const f32x2 xr = __builtin_convertvector(__builtin_convertvector(v, f16x2), f32x2);
+                                        const f32x2 c1 = {-0.1029432397f, -0.1029432397f}, c2 = {-2.302208199f, -2.302208199f};
+                                        const f32x2 t = xr * __builtin_elementwise_fma(xr * xr, c1, c2);  // -2 log2(e) u
+                                        const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+                                        f32x2 gl = xr * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+                                        asm("" : "+v"(gl));
+                                        o[2 * e2] = E::from_f32((float)(_Float16)gl[0]);
+                                        o[2 * e2 + 1] = E::from_f32((float)(_Float16)gl[1]);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        float v = DINO4_ACC(q, b, i, j)[e] + bb[e];
+                                        asm("" : "+v"(v));  // a real f32 sum: no "add, then round" fusion into v_fma_mixlo_f16
+                                        if constexpr (EPI == EPI_QKV) {
+                                            float vq = v * qs;
+                                            asm("" : "+v"(vq));
+                                            o[e] = E::from_f32(vq);
+                                        } else {
+                                            // EPI_SWIGLU: W rows interleaved in 32-blocks: column half 0 holds x1[32 units], half 1 x2 of the same units
+                                            const float h2 = DINO4_ACC(q, 1, i, j)[e] + b2[e];
+                                            float sg = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2;  // silu(x1) * x2
+                                            asm("" : "+v"(sg));
+                                            o[e] = E::from_f32(sg);
+                                        }
+                                    }
+                                }
+                                const int row = i * 16 + er;
+                                const int slot = (4 * b + 2 * j + (eq >> 1)) ^ (row & 7);  // 8 columns (16 B) per slot
+                                *(vec4*)(ep + row * 128 + slot * 16 + (eq & 1) * 8) = o;
+                            }
+                        }
+                    __builtin_amdgcn_wave_barrier();
+                    if constexpr (EPI == EPI_SWIGLU) {
+                        const int hid0 = (nw0 >> 6) * 32;  // 32 hidden units = 64 B per row: 4 lanes per row
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int row = it * 16 + (el >> 2), slot = el & 3;
+                            const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                            const int m = mbase + q * 64 + row;
+                            if (m < M && (NI == 8 || q * 64 + row < 16 * NI))
+                                *(u32x4*)((T*)p.out + (size_t)m * p.ldo + hid0 + slot * 8) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < 8; ++it) {
+                            const int row = it * 8 + (el >> 3), slot = el & 7;
+                            const u32x4 v = *(const u32x4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                            const int trw = q * 64 + row;  // token row within the wave's 16 NI
+                            const int m = mbase + trw;
+                            if (m < M && (NI == 8 || trw < 16 * NI))
+                                *(u32x4*)((T*)p.out + (size_t)m * p.ldo + nw0 + slot * 8) = v;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else {
+                // (4-byte outputs are handled after this loop: their passes are software-pipelined across both column groups)
+            }
+        }
+        if constexpr (EPI == EPI_RESID || EPI == EPI_PLAIN_F32) {
+            // 4-byte outputs: eight passes (column group cg, column half b, token half q) of 64 rows x 32 columns (128 B per row), each
+            // transposed through the wave's LDS slice and moved as whole lines.  The residual-stream rows of a pass are requested THREE
+            // passes ahead (the first three before anything else): with one wave per SIMD the read-modify-write burst is bound by how many
+            // lines a CU has in flight, and the loads of pass k + 3 are issued before the stores of pass k, so that waiting for them does
+            // not drain those stores (gfx950 retires loads and stores through one in-order counter).
+            constexpr int PF = 3;  // passes of residual rows in flight (x 32 VGPRs: four spill next to the next tile's 64 fragment registers)
+            float4 add[8][8];
+            auto pass_cols = [&](int ps8, int& nb, int& q) {
+                const int cg = ps8 >> 2, b = (ps8 >> 1) & 1;
+                q = ps8 & 1;
+                nb = n0 + wc * 128 + cg * 64 + b * 32 + (el & 7) * 4;
+            };
+            auto issue_loads = [&](int ps8) {
+                if constexpr (EPI == EPI_RESID) {
+                    int nb, q;
+                    pass_cols(ps8, nb, q);
+#pragma unroll
+                    for (int it = 0; it < 8; ++it) {
+                        int m = mbase + q * 64 + it * 8 + (el >> 3);
+                        m = m < M ? m : M - 1;
+                        add[ps8][it] = *(const float4*)((const float*)p.out + (size_t)m * p.ldo + nb);
+                    }
+                }
+            };
+#pragma unroll
+            for (int ps8 = 0; ps8 < PF; ++ps8) issue_loads(ps8);
+#pragma unroll
+            for (int ps8 = 0; ps8 < 8; ++ps8) {
+                const int cg = ps8 >> 2, b = (ps8 >> 1) & 1, q = ps8 & 1;
+                asm volatile("" : "+v"(el));  // per pass: row pointers are recomputed, not kept live across the eight passes
+                const int ncol = n0 + wc * 128 + cg * 64 + 4 * (el >> 4);
+                const int nb = n0 + wc * 128 + cg * 64 + b * 32 + (el & 7) * 4;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float4 ls = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if constexpr (EPI == EPI_RESID) ls = *(const float4*)(p.aux + ncol + b * 32 + j * 16);
+                    const float4 b4 = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (q == 1 && i >= NI1) continue;
+                        const int row = i * 16 + (el & 15);
+                        const int slot = (4 * j + (el >> 4)) ^ (row & 7);  // 4 columns (16 B) per slot
+                        const f32x4 a = DINO4_ACC(q, b, i, j);
+                        *(float4*)(ep + row * 128 + slot * 16) =
+                            make_float4((a[0] + b4.x) * ls.x, (a[1] + b4.y) * ls.y, (a[2] + b4.z) * ls.z, (a[3] + b4.w) * ls.w);
+                    }
+                }
+                if (ps8 + PF < 8) issue_loads(ps8 + PF);  // ahead of this pass's stores
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 8 + (el >> 3), slot = el & 7;
+                    float4 v = *(const float4*)(ep + row * 128 + ((slot ^ (row & 7)) << 4));
+                    if constexpr (EPI == EPI_RESID)
+                        v = make_float4(v.x + add[ps8][it].x, v.y + add[ps8][it].y, v.z + add[ps8][it].z, v.w + add[ps8][it].w);
+                    const int m = mbase + q * 64 + row;
+                    if (m < M && (NI == 8 || q * 64 + row < 16 * NI)) *(float4*)((float*)p.out + (size_t)m * p.ldo + nb) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+#undef DINO4_ACC
+    }  // persistent tile loop
+#undef DINO4_PIECE
+}
+
+#define DINO4_CLOCK_BEGIN(EPI)                                                                                  \
+    const bool cp_on__ = ((EPI) == EPI_GELU || (EPI) == EPI_SWIGLU) && blockIdx.x == 0 && threadIdx.x == 0;     \
+    unsigned long long cp_c0__ = 0, cp_r0__ = 0;                                                                \
+    if (cp_on__) {                                                                                              \
+        cp_c0__ = __builtin_readcyclecounter();                                                                 \
+        cp_r0__ = __builtin_amdgcn_s_memrealtime();                                                             \
+    }
+#define DINO4_CLOCK_END()                                                    \
+    if (cp_on__) {                                                           \
+        const unsigned long long r1__ = __builtin_amdgcn_s_memrealtime();    \
+        g_clock_probe4[0] = __builtin_readcyclecounter() - cp_c0__;          \
+        g_clock_probe4[1] = r1__ - cp_r0__;                                  \
+        g_clock_probe4[2] = r1__;                                            \
+    }
+
+template <typename T, int EPI, int NI>
+__global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DINO4_CLOCK_BEGIN(EPI)
+    gemm4_body<T, EPI, NI>(p, smem);
+    DINO4_CLOCK_END()
+}
+
+// One launch, two tile heights (gemm2_mixed_kernel's plan): every workgroup first walks its share of the 256-row tiles of `p` (whole
+// rounds), then its share of the 192-row tiles of `q` (the remaining rows); no grid-wide barrier in between.
+template <typename T, int EPI>
+__global__ __launch_bounds__(256) void gemm4_mixed_kernel(GemmArgs p, GemmArgs q) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    DINO4_CLOCK_BEGIN(EPI)
+    gemm4_body<T, EPI, 8>(p, smem);
+    gemm4_body<T, EPI, 6>(q, smem);
+    DINO4_CLOCK_END()
+}
+
+constexpr size_t G4_LDS = 163840;
+
+template <typename T, int NI>
+static hipError_t launch4_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    const int tiles = (a.N / 256) * ((a.M + 32 * NI - 1) / (32 * NI));
+    const dim3 grid(tiles < 256 ? tiles : 256), block(256);
+#define DINO_L4(E)                                                                \
+    case E:                                                                       \
+        hipLaunchKernelGGL((gemm4_kernel<T, E, NI>), grid, block, G4_LDS, st, a); \
+        break;
+    switch (epi) {
+        DINO_L4(EPI_QKV)
+        DINO_L4(EPI_RESID)
+        DINO_L4(EPI_GELU)
+        DINO_L4(EPI_SWIGLU)
+        DINO_L4(EPI_PLAIN_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef DINO_L4
+    return hipGetLastError();
+}
+
+template <typename T>
+static hipError_t launch4_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    const dim3 grid(256), block(256);
+#define DINO_LM4(E)                                                                    \
+    case E:                                                                            \
+        hipLaunchKernelGGL((gemm4_mixed_kernel<T, E>), grid, block, G4_LDS, st, a, b); \
+        break;
+    switch (epi) {
+        DINO_LM4(EPI_QKV)
+        DINO_LM4(EPI_RESID)
+        DINO_LM4(EPI_GELU)
+        DINO_LM4(EPI_SWIGLU)
+        DINO_LM4(EPI_PLAIN_F32)
+        default: return hipErrorInvalidValue;
+    }
+#undef DINO_LM4
+    return hipGetLastError();
+}
+
+// both require N % 256 == 0, K / 64 even and >= 4, and an epilogue other than EPI_PATCH (gemm4_ok)
+bool gemm4_ok(Epilogue epi, const GemmArgs& a) {
+    return epi != EPI_PATCH && a.N % 256 == 0 && a.K % 128 == 0 && a.K >= 256;
+}
+hipError_t launch_gemm4(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    return dt == DT_F16 ? launch4_t<_Float16, 8>(epi, a, st) : launch4_t<__bf16, 8>(epi, a, st);
+}
+// 256-row tiles for `a` (whole rounds), then 192-row tiles for `b`, in one launch
+hipError_t launch_gemm4_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st) {
+    return dt == DT_F16 ? launch4_mixed_t<_Float16>(epi, a, b, st) : launch4_mixed_t<__bf16>(epi, a, b, st);
+}
+
+template <typename T>
+static hipError_t attr4_t() {
+    hipError_t e = hipSuccess;
+#define DINO_A4(E)                                                                                                                        \
+    if (e == hipSuccess)                                                                                                                  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, E, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS); \
+    if (e == hipSuccess)                                                                                                                  \
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_mixed_kernel<T, E>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    DINO_A4(EPI_QKV)
+    DINO_A4(EPI_RESID)
+    DINO_A4(EPI_GELU)
+    DINO_A4(EPI_SWIGLU)
+    DINO_A4(EPI_PLAIN_F32)
+#undef DINO_A4
+    return e;
+}
+
+hipError_t gemm4_init() {
+    hipError_t e = attr4_t<_Float16>();
+    if (e == hipSuccess) e = attr4_t<__bf16>();
+    return e;
+}
+
+}  // namespace dinov2

@@ -250,10 +250,13 @@ namespace dinov2 { void pca_ritz(const double* yprev, const double* ynext, const
 // host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3, for the CPU test-suite
 // Effective shader clock under the dominant kernel: cycles and 100 MHz ticks of the last FFN-in GEMM launch (see gemm2.hip).
 extern "C" int dinov2_hip_op_clock_probe(uint64_t* cycles, uint64_t* ticks_100mhz) {
-    unsigned long long v[2] = {0, 0};
-    if (hipDeviceSynchronize() != hipSuccess || dinov2::gemm_clock_probe_read(v) != hipSuccess) return DINOV2_HIP_ERR_HIP;
-    if (cycles) *cycles = v[0];
-    if (ticks_100mhz) *ticks_100mhz = v[1];
+    unsigned long long v[3] = {0, 0, 0}, v4[3] = {0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess || dinov2::gemm_clock_probe_read(v) != hipSuccess ||
+        dinov2::gemm4_clock_probe_read(v4) != hipSuccess)
+        return DINOV2_HIP_ERR_HIP;
+    const unsigned long long* w = v4[2] > v[2] ? v4 : v;  // whichever generation of the kernel ran the last FFN-in launch
+    if (cycles) *cycles = w[0];
+    if (ticks_100mhz) *ticks_100mhz = w[1];
     return DINOV2_HIP_OK;
 }
 

@@ -469,3 +469,55 @@ def test_gemm_random_shapes_all_plans(api, seed):
     assert bad.mean() < (2e-4 if epi in (EPI_GELU, EPI_QKV) else 1e-7), f"M={M} N={N} K={K}: {bad.sum()} mismatches, first at {np.argwhere(bad)[:4]}"
 
 
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("epi", [EPI_QKV, EPI_RESID, EPI_GELU, EPI_SWIGLU, EPI_PLAIN])
+def test_gemm_generation_4_equals_generation_2_bit_for_bit(api, dt, epi, monkeypatch):
+    """gemm4.hip (four waves, accumulators in AGPRs, hand-ordered K loop) against gemm2.hip (eight waves, barrier-separated sections) on
+    the SAME plans: plan A (256-row tiles only: 2 panels x 2 column tiles, the last panel ragged), plan C (whole rounds of 256-row tiles +
+    192-row tiles in one launch, ragged last panel) and K / 64 = 4, 6 and 16.  Every output bit must agree (same MFMA, same K order, same
+    epilogue expressions), and the small-tile kernel's rows (M = 100) must be those bits too."""
+    rng = np.random.default_rng(40 + epi + dt)
+    for (M, N, K) in ((500, 512, 256), (17000, 1024, 384), (9300, 2048, 1024)):
+        Nout = N // 2 if epi == EPI_SWIGLU else N
+        X = _round(rng.standard_normal((100, K)), dt)
+        A = np.ascontiguousarray(np.tile(X, ((M + 99) // 100, 1))[:M])
+        W = _round(rng.standard_normal((N, K)) * 0.05, dt)
+        bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+        x0 = rng.standard_normal((100, Nout)).astype(np.float32) if epi == EPI_RESID else np.zeros((100, Nout), np.float32)
+        x0 = np.ascontiguousarray(np.tile(x0, ((M + 99) // 100, 1))[:M])
+        outs = {}
+        for gen in ("2", "4"):
+            monkeypatch.setenv("DINOV2_HIP_GEMM_GEN", gen)
+            out = x0.copy()
+            _gemm(api, dt, epi, A, W, bias, aux if epi == EPI_RESID else None, out, M, N, K, Nout, qcols=N // 4, qscale=0.125)
+            outs[gen] = out
+        monkeypatch.delenv("DINOV2_HIP_GEMM_GEN")
+        assert np.isfinite(outs["4"]).all()
+        assert np.array_equal(outs["2"], outs["4"]), (M, N, K)
+        small = x0[:100].copy()
+        _gemm(api, dt, epi, X, W, bias, aux if epi == EPI_RESID else None, small, 100, N, K, Nout, qcols=N // 4, qscale=0.125)
+        assert np.array_equal(small, outs["4"][:100]), (M, N, K)
+        assert np.array_equal(small, outs["4"][M - 100 - M % 100:M - M % 100]), (M, N, K)  # the last whole copy: another tile height
+
+
+def test_gemm_generation_4_race_screen(api):
+    """Fifty repeats of a multi-round launch of the four-wave kernel (plan C: 256- and 192-row tiles, next tile staged under the last
+    K-tiles and the epilogue) must reproduce the first result bit for bit: a fragment read ahead of its LDS-DMA data, or a buffer
+    re-staged under a reader, shows up as a rare differing tile."""
+    rng = np.random.default_rng(77)
+    M, N, K = 23000, 1024, 512
+    A = _round(rng.standard_normal((M, K)), F16)
+    W = _round(rng.standard_normal((N, K)) * 0.05, F16)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = np.zeros((M, N), np.float32)
+    _gemm(api, F16, EPI_PLAIN, A, W, bias, None, ref, M, N, K, N)
+    exp = (A[:256].astype(np.float64) @ W.astype(np.float64).T + bias)
+    np.testing.assert_allclose(ref[:256], exp, rtol=2e-5, atol=2e-4)
+    np.testing.assert_allclose(ref[-200:], A[-200:].astype(np.float64) @ W.astype(np.float64).T + bias, rtol=2e-5, atol=2e-4)
+    out = np.zeros_like(ref)
+    for _ in range(50):
+        out[:] = 0
+        _gemm(api, F16, EPI_PLAIN, A, W, bias, None, out, M, N, K, N)
+        assert np.array_equal(out, ref)
