@@ -330,9 +330,9 @@ def main():
         tfile = next(f for f in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
                      if os.path.exists(os.path.join(ROOT, "profiles", f)))
         tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
-        # FFN-in at this shape runs the mixed 256/192-row launch (gemm.hip plan C): one kernel per GEMM
-        syms = {"f16": ("gemm2_mixed_kernelIDF16_Li3E", "gemm2_kernelIDF16_Li3E"),
-                "bf16": ("gemm2_mixed_kernelIDF16bLi3E", "gemm2_kernelIDF16bLi3E")}[args.dtype]
+        # FFN-in at this shape runs the mixed 256/192-row launch (gemm.hip plan C): one kernel per GEMM -- gemm4.hip's since round 4
+        syms = {"f16": ("gemm4_mixed_kernelIDF16_Li3E", "gemm4_kernelIDF16_Li3E", "gemm2_mixed_kernelIDF16_Li3E", "gemm2_kernelIDF16_Li3E"),
+                "bf16": ("gemm4_mixed_kernelIDF16bLi3E", "gemm4_kernelIDF16bLi3E", "gemm2_mixed_kernelIDF16bLi3E", "gemm2_kernelIDF16bLi3E")}[args.dtype]
         hit = [v for sym in syms for k, v in tj.items() if sym in k][:1]
         if hit and args.model == "large" and B == 32 and not cfg["swiglu"]:
             traffic = round(hit[0]["hbm_bytes_per_launch_corrected"])

@@ -20,3 +20,8 @@ timeout 600 python bench.py --model small --no-cpu-baseline --steps 10 --warmup 
 timeout 900 python tools/readme_table.py > $O/readme_table.log 2>&1; tail -12 $O/readme_table.log; cp gpurun_out/readme_table.json $O/ 2>/dev/null
 timeout 600 python tools/host_path.py > $O/host_path.log 2>&1; tail -12 $O/host_path.log; cp gpurun_out/host_path.json $O/
 cp gpurun_out/parity_r04.json $O/parity.json 2>/dev/null
+# round 4: the N > 1 code path rehearsed on this one GPU (gloo, all ranks on device 0), the GEMM generations interleaved, the power-wall probes
+timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1 --master-port 29777 bench.py --gpus 8 --steps 3 --warmup 1 --windows 2 --warm-seconds 0 --backend gloo --batch 8 --no-cpu-baseline --no-latency > $O/bench_n8_gloo_dryrun.json 2> $O/bench_n8_dryrun.err; tail -c 600 $O/bench_n8_gloo_dryrun.json
+timeout 900 bash tools/ab_gen.sh > $O/ab_gen.txt 2>&1; cat $O/ab_gen.txt
+[ -x tools/probes/mfma_wall.bin ] && timeout 120 tools/probes/mfma_wall.bin > $O/mfma_wall.txt 2>&1
+[ -x tools/probes/gemm4w_prof.bin ] && timeout 200 tools/probes/gemm4w_prof.bin > $O/gemm4w_probe.txt 2>&1
