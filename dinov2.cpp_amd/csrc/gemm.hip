@@ -452,6 +452,7 @@ hipError_t gemm2_init();
 bool gemm4_ok(Epilogue epi, const GemmArgs& a);
 hipError_t launch_gemm4(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);
 hipError_t launch_gemm4_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st);
+hipError_t launch_gemm4_short(DType dt, Epilogue epi, const GemmArgs& a, int ni, hipStream_t st);  // 32 ni-row tiles, one per workgroup
 hipError_t gemm4_init();
 
 hipError_t gemm_init() {
@@ -612,6 +613,20 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         // fill the chip with 256- or 192-row tiles, enough columns that 128 x 256 tiles do (ViT-L batch 1 at 518 x 518: QKV 132 tiles
         // 18.0 -> 15.0 us, FFN-in 176 tiles 21.1 -> 17.6; ViT-g QKV 42 -> 24; batch 4 FFN-out 64 -> 51).  Below ~112 tiles the
         // small-tile kernel's many workgroups win, above 256 a second round starts (profiles/r03_small_m_gemm.md section 9).
+        // F4 (round 4): the same idea on gemm4.hip with the tile HEIGHT chosen for the launch: the shortest of 128 / 96 / 64 rows that still
+        // gives at most one tile per CU (QKV at ViT-L batch 1: 180 tiles of 96 rows instead of 132 of 128; FFN-in 240 instead of 176),
+        // for the 2-byte epilogues (profiles/r04_gemm4w.md section 6).  DINOV2_HIP_GEMM_GEN=2 keeps plan F.
+        {
+            const char* ge = getenv("DINOV2_HIP_GEMM_GEN");
+            const bool two_byte = epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU;
+            if (two_byte && !forced && !(ge && atoi(ge) == 2) && gemm4_ok(epi, a)) {
+                int ni = 0;
+                for (int c = 2; c <= 4 && !ni; ++c)
+                    if ((long)ntn * ((a.M + 32 * c - 1) / (32 * c)) <= 256) ni = c;
+                const long tiles = ni ? (long)ntn * ((a.M + 32 * ni - 1) / (32 * ni)) : 0;
+                if (ni && tiles >= 112) return launch_gemm4_short(dt, epi, a, ni, st);
+            }
+        }
         {
             const long t128r = (long)ntn * ((a.M + 127) / 128);
             if (!is_patch && !forced && t128r >= 112 && t128r <= 256) return launch_gemm2_128(dt, epi, a, st);

@@ -16,13 +16,14 @@
 //   16-byte chunks XOR-swizzled by (row >> 1) & 7 on the SOURCE side of the LDS-DMA and on the fragment reads); 4 x 8 KiB epilogue slices at
 //   128 KiB.
 //   Wave (wr, wc) = (wid >> 1, wid & 1): tokens [16 NI wr, + 16 NI) x columns [128 wc, + 128), NI x 8 blocks of 16 x 16 (NI = 8: 256-row
-//   tiles, 6: 192-row tiles for the partial last round, same launch -- gemm4_mixed_kernel), acc[i][j] in AGPRs; OPERAND SWAP as in
+//   tiles, 6: 192-row tiles for the partial last round, same launch -- gemm4_mixed_kernel; 2 / 3 / 4: 64- / 96- / 128-row tiles, one per
+//   workgroup, for launches that cannot fill the chip with taller ones -- batch 1), acc[i][j] in AGPRs; OPERAND SWAP as in
 //   gemm2.hip (weight fragment = MFMA A operand): a lane owns one token and four consecutive output columns.
 //   Fragment registers: P = k-step 0 of a K-tile (NI X + 8 W fragments of 4 VGPRs), Q = k-step 1.  MFMA order: column block j outer,
 //   token block i inner; MFMA index m = 64 ks + 8 j + i.
 //   K-tile t in buffer b = t & 1:
 //     m = 0, 2 .. 30   one ds_read_b128 of Q(t) behind every second MFMA (W fragments first)
-//     m = 8 k          one LDS-DMA piece (global_load_lds_dwordx4, 8 rows x 128 B) per 8 MFMAs: before barrier A the LAST pieces of K-tile
+//     m = 8 k          one LDS-DMA piece (global_load_lds_dwordx4, 8 rows x 128 B) per 8 MFMAs (short tiles: per 4): before barrier A the LAST pieces of K-tile
 //                      t + 1 (-> buffer b ^ 1), after it the FIRST pieces of K-tile t + 2 (-> buffer b): the staging of a K-tile spans one
 //                      whole K-tile time, and every piece has >= 1 000 matrix-pipe cycles to land
 //     m = 39           s_waitcnt lgkmcnt(0); s_barrier      [A] every wave has read all of buffer b
@@ -69,8 +70,6 @@ hipError_t gemm4_clock_probe_read(unsigned long long out[3]) {
 }
 
 constexpr int G4_PA = 39, G4_PB = 103;  // barrier A / B behind these MFMA indices
-constexpr int G4_NPRE = G4_PA / 8 + 1;  // staging slots (m = 8 k) up to barrier A: 5
-constexpr int G4_NB = (G4_PB - 8 * G4_NPRE) / 8 + 1;  // slots between the barriers: 8
 
 template <typename T, int EPI, int NI>
 static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem) {
@@ -80,10 +79,16 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
     using vec4 = typename E::vec4;
     constexpr bool F16 = std::is_same<T, _Float16>::value;
     constexpr int BM = 32 * NI, BN = 256;
-    constexpr int NI1 = NI - 4;        // 16-token blocks of a wave's second token half: 4 or 2
     constexpr int NP = NI + 8;         // LDS-DMA pieces per wave and K-tile: NI of X, 8 of W
-    constexpr int NPOST = 16 - G4_NPRE;  // slots behind barrier A: pieces 0 .. min(NP, NPOST) - 1 of the K-tile two ahead
-    static_assert(NP <= 16 && G4_NB <= NPOST && NP > NPOST, "staging schedule");
+    // staging slots at m = SP k: one per 8 MFMA indices for the tall tiles (a K-tile's staging spans one K-tile time); one per 4 for the
+    // short ones, whose K-tiles have 32 - 64 MFMAs (i < NI only) and give a piece little time to land: all of theirs go out right behind A
+    constexpr int SP = NI <= 4 ? 4 : 8;
+    constexpr int G4_NPRE = G4_PA / SP + 1;    // slots up to barrier A
+    constexpr int NSLOT = 128 / SP - G4_NPRE;  // slots behind barrier A
+    constexpr int NPOST = NP < NSLOT ? NP : NSLOT;  // pieces 0 .. NPOST - 1 of the K-tile two ahead go out behind barrier A, the rest before the next one
+    constexpr int NBS = (G4_PB - SP * G4_NPRE) / SP + 1;  // slots between the barriers
+    constexpr int G4_NB = NBS < NPOST ? NBS : NPOST;      // pieces issued between them: what barrier B's vmcnt leaves in flight
+    static_assert(NP - NPOST <= G4_NPRE, "staging schedule");
 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // opaque: nothing lane-derived is shared between the two bodies of gemm4_mixed_kernel
@@ -188,13 +193,13 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                 else DINO4_DSR(Qx[q - 8], xa[1], (q - 8) * 2048 + b * 32768);
             }
             // staging slots
-            if constexpr (m % 8 == 0) {
-                constexpr int k = m / 8;
+            if constexpr (m % SP == 0) {
+                constexpr int k = m / SP;
                 if constexpr (k < G4_NPRE) {
                     if constexpr (NPOST + k < NP) {
                         if (pre_on) DINO4_PIECE(NPOST + k, kt_pre, b ^ 1)
                     }
-                } else {
+                } else if constexpr (k - G4_NPRE < NPOST) {
                     if (post_on) DINO4_PIECE(k - G4_NPRE, kt_post, b)
                 }
             }
@@ -297,6 +302,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                 constexpr int BN_ = EPI == EPI_SWIGLU ? 1 : 2;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
+                    if (q * 4 >= NI) continue;  // (tiles of at most 128 rows: one token half)
 #pragma unroll
                     for (int b = 0; b < BN_; ++b)
 #pragma unroll
@@ -305,7 +311,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                             const float b2[4] = {bs[1][j].x, bs[1][j].y, bs[1][j].z, bs[1][j].w};
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
-                                if (q == 1 && i >= NI1) continue;  // 192-row tiles: the second pass has 32 rows
+                                if (q * 4 + i >= NI) continue;  // shorter tiles: fewer 16-token blocks
                                 vec4 o;
                                 if constexpr (EPI == EPI_GELU) {
                                     // ggml semantics: y = table[f16(x)], table[h] = f16(gelu_tanh(f32(h))); two columns per instruction
@@ -407,6 +413,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
 #pragma unroll
             for (int ps8 = 0; ps8 < 8; ++ps8) {
                 const int cg = ps8 >> 2, b = (ps8 >> 1) & 1, q = ps8 & 1;
+                if (q * 4 >= NI) continue;
                 asm volatile("" : "+v"(el));  // per pass: row pointers are recomputed, not kept live across the eight passes
                 const int ncol = n0 + wc * 128 + cg * 64 + 4 * (el >> 4);
                 const int nb = n0 + wc * 128 + cg * 64 + b * 32 + (el & 7) * 4;
@@ -417,7 +424,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                     const float4 b4 = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        if (q == 1 && i >= NI1) continue;
+                        if (q * 4 + i >= NI) continue;
                         const int row = i * 16 + (el & 15);
                         const int slot = (4 * j + (el >> 4)) ^ (row & 7);  // 4 columns (16 B) per slot
                         const f32x4 a = DINO4_ACC(q, b, i, j);
@@ -531,6 +538,36 @@ hipError_t launch_gemm4_mixed(DType dt, Epilogue epi, const GemmArgs& a, const G
     return dt == DT_F16 ? launch4_mixed_t<_Float16>(epi, a, b, st) : launch4_mixed_t<__bf16>(epi, a, b, st);
 }
 
+// Short tiles (64 / 96 / 128 rows), one per workgroup: for launches whose 256-row tiles would leave most CUs idle (batch 1: M = 1 374 ->
+// QKV 15 panels of 96 rows x 12 column tiles = 180 workgroups instead of 132 of 128 rows; FFN-in 240 instead of 176).  The 2-byte
+// epilogues only (the f32 ones go to the small-tile kernel at these sizes).  Same K order, same bits.
+template <typename T, int NI>
+static hipError_t launch4_short_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    const int tiles = (a.N / 256) * ((a.M + 32 * NI - 1) / (32 * NI));
+    if (tiles > 256) return hipErrorInvalidValue;  // (one tile per workgroup, one workgroup per CU)
+    const dim3 grid(tiles), block(256);
+    switch (epi) {
+        case EPI_QKV: hipLaunchKernelGGL((gemm4_kernel<T, EPI_QKV, NI>), grid, block, G4_LDS, st, a); break;
+        case EPI_GELU: hipLaunchKernelGGL((gemm4_kernel<T, EPI_GELU, NI>), grid, block, G4_LDS, st, a); break;
+        case EPI_SWIGLU: hipLaunchKernelGGL((gemm4_kernel<T, EPI_SWIGLU, NI>), grid, block, G4_LDS, st, a); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+// rows per tile = 32 ni, ni in {2, 3, 4}
+hipError_t launch_gemm4_short(DType dt, Epilogue epi, const GemmArgs& a, int ni, hipStream_t st) {
+    if (dt == DT_F16) return ni == 2 ? launch4_short_t<_Float16, 2>(epi, a, st) : ni == 3 ? launch4_short_t<_Float16, 3>(epi, a, st) : launch4_short_t<_Float16, 4>(epi, a, st);
+    return ni == 2 ? launch4_short_t<__bf16, 2>(epi, a, st) : ni == 3 ? launch4_short_t<__bf16, 3>(epi, a, st) : launch4_short_t<__bf16, 4>(epi, a, st);
+}
+
+template <typename T, int NI>
+static hipError_t attr4_short_t() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_QKV, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_GELU, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_SWIGLU, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    return e;
+}
+
 template <typename T>
 static hipError_t attr4_t() {
     hipError_t e = hipSuccess;
@@ -551,6 +588,12 @@ static hipError_t attr4_t() {
 hipError_t gemm4_init() {
     hipError_t e = attr4_t<_Float16>();
     if (e == hipSuccess) e = attr4_t<__bf16>();
+    if (e == hipSuccess) e = attr4_short_t<_Float16, 2>();
+    if (e == hipSuccess) e = attr4_short_t<_Float16, 3>();
+    if (e == hipSuccess) e = attr4_short_t<_Float16, 4>();
+    if (e == hipSuccess) e = attr4_short_t<__bf16, 2>();
+    if (e == hipSuccess) e = attr4_short_t<__bf16, 3>();
+    if (e == hipSuccess) e = attr4_short_t<__bf16, 4>();
     return e;
 }
 

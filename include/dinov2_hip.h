@@ -234,7 +234,7 @@ int dinov2_hip_debug_hidden(dinov2_hip_session *session, const dinov2_hip_input 
 int dinov2_hip_abi_version(void);
 
 /* -- Environment ----------------------------------------------------------------------------------------------------------
- * The library reads exactly six environment variables; none is needed in normal use.
+ * The library reads exactly seven environment variables; none is needed in normal use.
  *   DINOV2_HIP_GRAPHS=1      replay a captured hipGraph for a forward that repeats with the same session, input pointer, shape
  *                            and flags (second sighting is captured).  Off by default: the forward is kernel-bound and the
  *                            replay measured no faster on an idle host; it is there for hosts whose launch thread is contended.
@@ -246,6 +246,9 @@ int dinov2_hip_abi_version(void);
  *                            chosen by shape): the bit-equality tests of the kernels use them.
  *   DINOV2_HIP_ATTN_NWV=2|3|4  testing aid: waves (32-query blocks) per workgroup of the software-pipelined attention kernel (normally 4;
  *                            2 for short sequences); every size gives the same bits.
+ *   DINOV2_HIP_GEMM_GEN=2|4  testing aid: which generation of the persistent GEMM runs the 256-row / mixed plans -- 2 = gemm2.hip (eight waves,
+ *                            barrier-separated sections), 4 = gemm4.hip (four waves, hand-ordered K loop; the default wherever it applies).
+ *                            Both give every row the same bits; read per launch.
  *   DINOV2_HIP_GROUP_REQUIRE_RCCL=1  dinov2_hip_group_create fails when librccl cannot be loaded instead of letting every device
  *                            read the GGUF itself.
  * (DINOV2_HIP_LIB, read by the Python binding only, points it at another build of this library.) */
