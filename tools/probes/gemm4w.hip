@@ -129,6 +129,16 @@ static __device__ __forceinline__ void gemm4w_body(const _Float16* __restrict__ 
 
     f32x4 acc[8][8];
     u32x4 Px[8], Pw[8], Qx[8], Qw[8];
+#ifdef CPK
+    // -DCPK=<n>: n GELU-shaped filler chains per K-tile (13 one- or two-instruction stages each, two elements per chain, every stage pinned
+    // into its own MFMA shadow by an empty volatile asm on its result): what a DEFERRED epilogue's arithmetic costs the K loop that carries it.
+    // 8 chains per K-tile x 16 K-tiles = the 256 elements per lane of a whole 256 x 256 tile.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    f32x2 fa[3], fb[3], fc[3];
+    unsigned fsink = 0;
+    f32x2 fseed = {(float)(tid & 31) * 0.05f - 0.8f, (float)(tid & 15) * 0.07f - 0.5f};
+#endif
     if (VARIANT & 2) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) Px[i] = Pw[i] = Qx[i] = Qw[i] = u32x4{(unsigned)tid, 1u, 2u, 3u};
@@ -153,9 +163,14 @@ static __device__ __forceinline__ void gemm4w_body(const _Float16* __restrict__ 
     static constexpr int NPOST = 16 - NPRE;
     static constexpr int NB = (PB - (S0 + 8 * NPRE)) / 8 + 1;  // slots in (PA, PB]: pieces issued between barrier A and barrier B
     static_assert(S0 < 8 && NPRE >= 1 && NPRE < 16 && NB >= 1 && NB <= NPOST, "schedule constants");
-    auto ktile = [&acc, &Px, &Pw, &Qx, &Qw, &xa, &wa, &so, &ldsp, Ab, Wb](auto bc, auto firstc, int kt_pre, bool pre_on, auto&& at_a, int kt_post,
+    #ifdef CPK
+#define FCAP , &fa, &fb, &fc, &fsink, &fseed
+#else
+#define FCAP
+#endif
+    auto ktile = [&acc, &Px, &Pw, &Qx, &Qw, &xa, &wa, &so, &ldsp, Ab, Wb FCAP](auto bc, auto firstc, int kt_pre, bool pre_on, auto&& at_a, int kt_post,
                                                                          bool post_on, bool do_readp) {
-        static_for<128>([&acc, &Px, &Pw, &Qx, &Qw, &xa, &wa, &so, &ldsp, Ab, Wb, &kt_pre, &pre_on, &at_a, &kt_post, &post_on, &do_readp, bc,
+        static_for<128>([&acc, &Px, &Pw, &Qx, &Qw, &xa, &wa, &so, &ldsp, Ab, Wb FCAP, &kt_pre, &pre_on, &at_a, &kt_post, &post_on, &do_readp, bc,
                          firstc](auto mc) {
             constexpr int m = decltype(mc)::value;
             constexpr int b = decltype(bc)::value;
@@ -167,6 +182,27 @@ static __device__ __forceinline__ void gemm4w_body(const _Float16* __restrict__ 
             } else {
                 MFMA_ACC(acc[i][j], Qw[j], Qx[i]);
             }
+#ifdef CPK
+            {
+                constexpr int SPACING = 104 / CPK;  // chain c starts at m = 4 + SPACING c and runs 13 consecutive slots
+                static_for<CPK>([&fa, &fb, &fc, &fsink, &fseed, mc](auto cc) {
+                    constexpr int c = decltype(cc)::value, m = decltype(mc)::value;
+                    constexpr int st = m - 4 - SPACING * c, r = c % 3;
+                    if constexpr (st == 0) { fa[r] = fseed + f32x2{0.01f * c, -0.02f * c}; asm volatile("" : "+v"(fa[r])); }
+                    else if constexpr (st == 1) { f16x2 h = __builtin_convertvector(fa[r], f16x2); fa[r] = __builtin_convertvector(h, f32x2); asm volatile("" : "+v"(fa[r])); }
+                    else if constexpr (st == 2) { fb[r] = fa[r] * fa[r]; asm volatile("" : "+v"(fb[r])); }
+                    else if constexpr (st == 3) { fb[r] = __builtin_elementwise_fma(fb[r], f32x2{-0.1029432397f, -0.1029432397f}, f32x2{-2.302208199f, -2.302208199f}); asm volatile("" : "+v"(fb[r])); }
+                    else if constexpr (st == 4) { fb[r] = fa[r] * fb[r]; asm volatile("" : "+v"(fb[r])); }
+                    else if constexpr (st == 5) { fc[r][0] = __builtin_amdgcn_exp2f(fb[r][0]); asm volatile("" : "+v"(fc[r])); }
+                    else if constexpr (st == 6) { fc[r][1] = __builtin_amdgcn_exp2f(fb[r][1]); asm volatile("" : "+v"(fc[r])); }
+                    else if constexpr (st == 7) { fc[r] = fc[r] + f32x2{1.0f, 1.0f}; asm volatile("" : "+v"(fc[r])); }
+                    else if constexpr (st == 8) { fc[r][0] = __builtin_amdgcn_rcpf(fc[r][0]); asm volatile("" : "+v"(fc[r])); }
+                    else if constexpr (st == 9) { fc[r][1] = __builtin_amdgcn_rcpf(fc[r][1]); asm volatile("" : "+v"(fc[r])); }
+                    else if constexpr (st == 10) { fa[r] = fa[r] * fc[r]; asm volatile("" : "+v"(fa[r])); }
+                    else if constexpr (st == 11) { f16x2 h = __builtin_convertvector(fa[r], f16x2); fsink ^= __builtin_bit_cast(unsigned, h); asm volatile("" : "+v"(fsink)); }
+                });
+            }
+#endif
             // Q(t): k-step 1 of this K-tile (W fragments first: their registers have been free longest)
             if constexpr (m % QSTRIDE == 0 && m / QSTRIDE < 16) {
                 constexpr int q = m / QSTRIDE;
@@ -284,6 +320,9 @@ static __device__ __forceinline__ void gemm4w_body(const _Float16* __restrict__ 
             });
         });
     }
+#ifdef CPK
+    if (fsink == 0x12345u) C[0] = 1.0f;  // (keeps the filler chains alive)
+#endif
 #undef PIECE
 }
 
@@ -384,7 +423,13 @@ static void run(int M, int N, int K, int iters) {
                            204800.0 / (cyc / kt), rt / kt * 0.01, cyc / rt / 10.0);
     }
 #endif
-    printf("gemm4w v%d A%d B%d Q%d S%d M=%d N=%d K=%d: %.4f ms (best %.4f)  %.1f TFLOP/s  (%.3f us per K-tile-round)  refcheck max|d| = %.3g %s  reruns differing: %d\n",
+    printf("gemm4w cpk%d v%d A%d B%d Q%d S%d M=%d N=%d K=%d: %.4f ms (best %.4f)  %.1f TFLOP/s  (%.3f us per K-tile-round)  refcheck max|d| = %.3g %s  reruns differing: %d\n",
+           
+#ifdef CPK
+           CPK,
+#else
+           0,
+#endif
            VARIANT, PA, PB, QSTRIDE, STAG, M, N, K, ms, best, 2.0 * M * N * K / ms / 1e9,
            ms * 1e3 / ((double)(K / 64) * ((tiles + 255) / 256)), worst, worst < 2e-2 * std::sqrt((double)K / 1024) ? "OK" : "MISMATCH", diffs);
     hipFree(A); hipFree(W); hipFree(C); hipFree(dm); hipFree(dn); hipFree(dr);
