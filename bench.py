@@ -212,12 +212,13 @@ def main():
         dist.barrier()
     elapsed = float(np.median(window_s))
     # the clock the part sustained inside the dominant kernel of the last window (rank 0's device)
-    eff_clock = None
+    eff_clock = dom_dev_ms = None
     try:
         import ctypes
         cyc, tk = ctypes.c_uint64(0), ctypes.c_uint64(0)
         if api.lib().dinov2_hip_op_clock_probe(ctypes.byref(cyc), ctypes.byref(tk)) == 0 and tk.value > 0:
             eff_clock = round(cyc.value / (tk.value * 10.0), 4)  # cycles per ns
+            dom_dev_ms = tk.value * 1e-5  # what workgroup 0 (persistent: first tile to last) spent inside that launch, device clock
     except Exception:
         eff_clock = None
     if not bool(torch.isfinite(probs).all()):
@@ -343,6 +344,10 @@ def main():
                 "traffic_note": "HBM-side bytes/launch from rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r0N_hbm_traffic.json, newest round); "
                                 "algorithmic bytes/launch = %d" % int(2 * M * H + 2 * H * F + 2 * M * F),
                 "flops_per_launch": flops_launch[dom], "avg_launch_ms": kernels.get(dom, {}).get("avg_ms"),
+                # cross-check without the two events a profiled launch carries (they add ~ 5 us of gaps per launch; rocprofv3's average
+                # sits between the two): the same kernel's last launch of the timed windows on the device's own 100 MHz clock
+                "in_kernel_ms_device_clock": None if not dom_dev_ms else round(dom_dev_ms, 4),
+                "achieved_by_device_clock": None if not dom_dev_ms else round(flops_launch[dom] / (dom_dev_ms * 1e-3) / 1e12, 1),
                 "whole_forward_tflops": round(value / world * gflop_img / 1e3, 1),
                 "whole_forward_frac": round(value / world * gflop_img / 1e3 / MFMA_PEAK_TFLOPS, 4),
                 # context, not the contract's peak: what v_mfma_f32_32x32x16_f16 alone sustains on random f16 operands on
