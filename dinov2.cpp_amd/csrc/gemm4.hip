@@ -71,6 +71,23 @@ hipError_t gemm4_clock_probe_read(unsigned long long out[3]) {
 
 constexpr int G4_PA = 39, G4_PB = 103;  // barrier A / B behind these MFMA indices
 
+// -DDINO_GEMM4_PROF (tuning builds): s_memtime sums per workgroup of wave 0 -- [0] K loops, [1] epilogues, [2] tiles, [3] the 100 MHz ticks of
+// both -- printed by the launcher after each launch.
+#ifdef DINO_GEMM4_PROF
+__device__ unsigned long long g_gemm4_prof[256 * 4];
+#define DINO4_GP_DECL unsigned long long gp_t = 0, gp_r = 0, gp_acc[4] = {0, 0, 0, 0};
+#define DINO4_GP_START { gp_t = __builtin_readcyclecounter(); gp_r = __builtin_amdgcn_s_memrealtime(); }
+#define DINO4_GP(i) { const unsigned long long t__ = __builtin_readcyclecounter(); gp_acc[i] += t__ - gp_t; gp_t = t__; }
+#define DINO4_GP_TILE { gp_acc[2] += 1; const unsigned long long r__ = __builtin_amdgcn_s_memrealtime(); gp_acc[3] += r__ - gp_r; gp_r = r__; }
+#define DINO4_GP_FLUSH if (threadIdx.x == 0) for (int i__ = 0; i__ < 4; ++i__) g_gemm4_prof[blockIdx.x * 4 + i__] += gp_acc[i__];
+#else
+#define DINO4_GP_DECL
+#define DINO4_GP_START
+#define DINO4_GP(i)
+#define DINO4_GP_TILE
+#define DINO4_GP_FLUSH
+#endif
+
 template <typename T, int EPI, int NI>
 static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem) {
     // (no implicit mul+add -> fma contraction: an element's bits must not depend on where its row sits in a tile -- see gemm2.hip)
@@ -90,6 +107,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
     constexpr int G4_NB = NBS < NPOST ? NBS : NPOST;      // pieces issued between them: what barrier B's vmcnt leaves in flight
     static_assert(NP - NPOST <= G4_NPRE, "staging schedule");
 
+    DINO4_GP_DECL
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));  // opaque: nothing lane-derived is shared between the two bodies of gemm4_mixed_kernel
     const int lane = tid & 63;
@@ -255,6 +273,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
         int m0, n0;
         tile_mn(chunk0 + tix, m0, n0);
         const bool has_next = tix + nb_x < chunkn;
+        DINO4_GP_START
 
         // K-tiles 0, 1 (accumulators from zero), the middle, and the last two, under which the staging crosses over to the next output tile
         ktile(T0{}, TT{}, 1, true, nop, 2, true, true);
@@ -274,6 +293,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
               },
               0, has_next, true);
         ktile(T1{}, TF{}, 0, has_next, nop, 1, has_next, has_next);
+        DINO4_GP(0)
 
         // ---- epilogue (gemm2.hip's, per 64-column group cg of the wave's 128 columns): each wave transposes its result through a private
         // 8 KiB LDS slice and moves whole 128-byte lines.  Slice image: 64 rows x 128 B, 16-byte slot s of row r stored at s ^ (r & 7).
@@ -447,7 +467,10 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
             }
         }
 #undef DINO4_ACC
+        DINO4_GP(1)
+        DINO4_GP_TILE
     }  // persistent tile loop
+    DINO4_GP_FLUSH
 #undef DINO4_PIECE
 }
 
@@ -487,6 +510,21 @@ __global__ __launch_bounds__(256) void gemm4_mixed_kernel(GemmArgs p, GemmArgs q
 
 constexpr size_t G4_LDS = 163840;
 
+#ifdef DINO_GEMM4_PROF
+static void gemm4_prof_dump(const char* what, int epi, int nblocks) {
+    static unsigned long long h[256 * 4], z[256 * 4];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_gemm4_prof), sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_gemm4_prof), z, sizeof z);
+    double a[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nblocks; ++b)
+        for (int i = 0; i < 4; ++i) a[i] += (double)h[b * 4 + i];
+    const double t = a[2] > 0 ? a[2] : 1;
+    fprintf(stderr, "gemm4_prof %s epi %d: per tile (wave 0): K loop %.0f cycles, epilogue %.0f cycles, %.2f us in all (%.2f tiles per workgroup) -> clock %.3f GHz\n", what, epi,
+            a[0] / t, a[1] / t, a[3] / t * 0.01, a[2] / nblocks, (a[0] + a[1]) / (a[3] * 10.0));
+}
+#endif
+
 template <typename T, int NI>
 static hipError_t launch4_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int tiles = (a.N / 256) * ((a.M + 32 * NI - 1) / (32 * NI));
@@ -504,6 +542,9 @@ static hipError_t launch4_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         default: return hipErrorInvalidValue;
     }
 #undef DINO_L4
+#ifdef DINO_GEMM4_PROF
+    gemm4_prof_dump("plain launch", (int)epi, (int)grid.x);
+#endif
     return hipGetLastError();
 }
 
@@ -523,6 +564,9 @@ static hipError_t launch4_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArg
         default: return hipErrorInvalidValue;
     }
 #undef DINO_LM4
+#ifdef DINO_GEMM4_PROF
+    gemm4_prof_dump("mixed launch", (int)epi, 256);
+#endif
     return hipGetLastError();
 }
 
