@@ -503,8 +503,19 @@ template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm4_mixed_kernel(GemmArgs p, GemmArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DINO4_CLOCK_BEGIN(EPI)
-    gemm4_body<T, EPI, 8>(p, smem);
-    gemm4_body<T, EPI, 6>(q, smem);
+#ifdef DINO_GEMM4_DEPHASE
+    // XCDs of odd index take their 192-row tiles FIRST: a quarter of a tile time out of phase with the even ones for the rest of the launch, so
+    // that the chip's epilogue bursts (stores, residual read-modify-write) come as two half-size ones.  All workgroups of an XCD stay in step
+    // (they share operand panels in its L2).  Scheduling only: every tile is computed by the same code either way.
+    if ((blockIdx.x & 7) & 1) {
+        gemm4_body<T, EPI, 6>(q, smem);
+        gemm4_body<T, EPI, 8>(p, smem);
+    } else
+#endif
+    {
+        gemm4_body<T, EPI, 8>(p, smem);
+        gemm4_body<T, EPI, 6>(q, smem);
+    }
     DINO4_CLOCK_END()
 }
 
