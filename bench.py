@@ -77,6 +77,9 @@ def main():
     args = ap.parse_args()
     args.windows = max(1, args.windows)
 
+    # the pool's host driver only supports dmabuf IPC: without this RCCL's cross-process buffer sharing fails (hipIpcGetMemHandle);
+    # already exported on the GPU boxes, set here as well so that a bare `torchrun bench.py` does not depend on the shell
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch  # plumbing only: device memory for the inputs, torch.distributed (RCCL) for N > 1
     from __graft_entry__ import PKG_NAME, load_package
     pkg = load_package()
