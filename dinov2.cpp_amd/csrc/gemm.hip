@@ -619,7 +619,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         {
             const char* ge = getenv("DINOV2_HIP_GEMM_GEN");
             const bool two_byte = epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU;
-            if (two_byte && !forced && !(ge && atoi(ge) == 2) && gemm4_ok(epi, a)) {
+            if (two_byte && !forced && !(ge && atoi(ge) == 2) && gemm4_ok(epi, a) && ((ge && atoi(ge) == 4) || a.K >= 1024)) {
                 int ni = 0;
                 for (int c = 2; c <= 4 && !ni; ++c)
                     if ((long)ntn * ((a.M + 32 * c - 1) / (32 * c)) <= 256) ni = c;
@@ -638,7 +638,10 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         const int gen = gen_env ? atoi(gen_env) : 0;
         // default: gemm4.hip wherever it applies (in the model: FFN-out - 4 %, QKV and FFN-in within 0.5 %, attn-out + 2 %; forward + 0.8 %
         // over gemm2.hip everywhere, same box, interleaved runs -- profiles/r04_gemm4w.md)
-        const bool g4 = gen != 2 && gemm4_ok(epi, a);
+        // ... for K >= 1 024: with fewer K-tiles per output tile the four-wave kernel's longer epilogue (one wave per SIMD issues it alone)
+        // outweighs its K loop -- ViT-B / ViT-S (K = 768 / 384) measured 1.4 % / 3 % faster on gemm2.hip, ViT-L / ViT-g on gemm4.hip.
+        // DINOV2_HIP_GEMM_GEN=4 forces gemm4.hip wherever it can run (tests).
+        const bool g4 = gen != 2 && gemm4_ok(epi, a) && (gen == 4 || a.K >= 1024);
         switch (plan) {
             case 'A': return g4 ? launch_gemm4(dt, epi, a, st) : launch_gemm2(dt, epi, a, st);
             case 'B': return launch_gemm2_192(dt, epi, a, st);
