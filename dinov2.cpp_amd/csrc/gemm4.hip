@@ -1,8 +1,8 @@
 // gemm4.hip -- fourth generation of the f16/bf16 MFMA GEMM: the 256 x 256 x 64 tile on FOUR waves (one per SIMD, 512 registers each: 256
 // accumulators in AGPRs + fragments in VGPRs), every wave a 128 x 128 output block, the K loop ONE hand-ordered instruction stream per
 // wave.  Same contract, epilogues, K order (a row's bits are those of gemm.hip / gemm2.hip) and XCD-aware persistent tile walk as
-// gemm2.hip, which stays for the shapes this kernel does not take (K / 64 < 4, the patch-embed epilogue, 128-row one-tile-per-workgroup
-// launches).
+// gemm2.hip, which stays for the launches this kernel is not given (K < 1 024, where its shorter epilogue wins -- launch_gemm in gemm.hip --
+// the patch-embed epilogue, the 192-row-only plan).
 //
 // Why (profiles/r04_gemm4w.md): gemm2.hip's K loop runs barrier-separated MEM / MMA sections shared by the two waves of a SIMD and
 // reaches ~75 % matrix-pipe duty; the vendor's assembly kernel of the same macro tile is a single wave per SIMD issuing its 128 MFMAs per
