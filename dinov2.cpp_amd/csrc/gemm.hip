@@ -641,7 +641,9 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st
         // ... for K >= 1 024: with fewer K-tiles per output tile the four-wave kernel's longer epilogue (one wave per SIMD issues it alone)
         // outweighs its K loop -- ViT-B / ViT-S (K = 768 / 384) measured 1.4 % / 3 % faster on gemm2.hip, ViT-L / ViT-g on gemm4.hip.
         // DINOV2_HIP_GEMM_GEN=4 forces gemm4.hip wherever it can run (tests).
-        const bool g4 = gen != 2 && gemm4_ok(epi, a) && (gen == 4 || a.K >= 1024);
+        // ... and not the residual epilogue at K < 2 048 (attn-out: its read-modify-write burst is 36 % of a tile and eight waves keep more
+        // of it in flight: 0.131 against 0.133 ms in the model, four interleaved runs).
+        const bool g4 = gen != 2 && gemm4_ok(epi, a) && (gen == 4 || (a.K >= 1024 && !(epi == EPI_RESID && a.K < 2048)));
         switch (plan) {
             case 'A': return g4 ? launch_gemm4(dt, epi, a, st) : launch_gemm2(dt, epi, a, st);
             case 'B': return launch_gemm2_192(dt, epi, a, st);
