@@ -495,8 +495,13 @@ hipError_t gemm_init() {
 //   E  small-tile kernel only                               outputs / (256 tiles) / 0.5
 // Measured (M = 43 968): QKV 0.292 -> 0.285 ms (D), out-proj 0.129 -> 0.125 (C), FFN-out 0.393 -> 0.374 (C); ViT-g bf16 batch 8
 // 221 -> 244 images/s.  DINOV2_HIP_GEMM_TILE=128|256 forces E / A (testing aid: include/dinov2_hip.h, "Environment").
-hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st) {
+hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t st) {
+    GemmArgs a = a_in;
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
+    // 2-byte outputs larger than the chip's L2s (8 x 4 MiB) leave with non-temporal stores: they would only evict the operand panels, and
+    // their consumer (another kernel) reads them through the memory side; smaller ones (batch 1) are found in L2 by the next kernel
+    if (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU)
+        a.nt_out = (size_t)a.M * (size_t)(epi == EPI_SWIGLU ? a.N / 2 : a.N) * 2 > ((size_t)48 << 20) ? 1 : 0;
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
     // rows are fetched with 16-byte global -> LDS DMA pieces and 16-byte vector loads: strides must keep rows 16-byte aligned

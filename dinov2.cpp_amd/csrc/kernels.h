@@ -32,6 +32,7 @@ struct GemmArgs {
     int qcols;          // EPI_QKV: columns [0, qcols) are multiplied by qscale
     float qscale;
     int small_only;     // launch_gemm internal: this is the tail of a split launch, use the small-tile kernel
+    int nt_out;         // launch_gemm internal: 2-byte outputs leave with non-temporal stores (set when the output is larger than the L2s)
 };
 
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);
