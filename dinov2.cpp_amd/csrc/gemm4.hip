@@ -138,7 +138,10 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
     const int tq = ntiles >> 3, tr = ntiles & 7;
     const int chunk0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
     const int chunkn = tq + (xcd < tr ? 1 : 0);
-    constexpr int GM = 8;
+#ifndef DINO_GEMM4_GM
+#define DINO_GEMM4_GM 8  // (tuning builds: 4 | 16)
+#endif
+    constexpr int GM = DINO_GEMM4_GM;
     auto tile_mn = [&](int lid, int& m0, int& n0) {
         const int g = lid / (GM * ntn), r = lid - g * (GM * ntn);
         const int gm = ntm - g * GM < GM ? ntm - g * GM : GM;
