@@ -69,6 +69,22 @@ class GroupOpts(C.Structure):
 _lib = None
 
 
+def set_tuning(key, value):
+    """Testing aid (include/dinov2_hip_ops.h): flip one of the library's tuning switches inside this process; 0 = its own choice."""
+    rc = lib().dinov2_hip_op_set_tuning(key.encode(), int(value))
+    if rc != 0:
+        raise ValueError(f"unknown tuning key {key!r}")
+
+
+def gemm_plan(dtype, epilogue, M, N, K):
+    """The kernel plan launch_gemm picks for a shape (text; no device needed)."""
+    buf = C.create_string_buffer(256)
+    rc = lib().dinov2_hip_op_gemm_plan(int(dtype), int(epilogue), int(M), int(N), int(K), buf, 256)
+    if rc != 0:
+        raise ValueError(f"launch_gemm refuses dtype={dtype} epilogue={epilogue} M={M} N={N} K={K}")
+    return buf.value.decode()
+
+
 def lib():
     """Load libdinov2_hip.so; raise loudly if it is not built (no CPU fallback exists)."""
     global _lib
@@ -147,6 +163,9 @@ def lib():
     L.dinov2_hip_op_gemm_bench.restype = C.c_float
     L.dinov2_hip_op_attention_bench.argtypes = [i32] * 6
     L.dinov2_hip_op_attention_bench.restype = C.c_float
+    L.dinov2_hip_op_set_tuning.argtypes = [cp, i32]
+    L.dinov2_hip_op_get_tuning.argtypes = [cp]
+    L.dinov2_hip_op_gemm_plan.argtypes = [i32, i32, i32, i32, i32, C.c_char_p, i32]
     _lib = L
     return L
 

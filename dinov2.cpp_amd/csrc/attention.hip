@@ -867,8 +867,7 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
     // VGPRs, four workgroups per CU hide each other's latencies (0.296 ms vs 0.31-0.32).  Few (batch 1: 176): nothing to
     // overlap with, so the per-wave dependency chain decides and the software-pipelined attention2_kernel wins (22 vs 26 us).
     // DINOV2_HIP_ATTN_V=1|2 forces one (testing aid, include/dinov2_hip.h "Environment": the two kernels must agree bit for bit).
-    const char* ev = getenv("DINOV2_HIP_ATTN_V");  // read per launch: the test flips it
-    const int forced_ver = ev ? atoi(ev) : 0;
+    const int forced_ver = tune_get(TUNE_ATTN_V);  // (read from the environment once; the tests use dinov2_hip_op_set_tuning)
     const long units = (long)((T + 127) / 128) * nh * B;
     const int ver = forced_ver ? forced_ver : units <= 512 ? 2 : 1;
     if (ver == 2) {
@@ -877,8 +876,7 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
         // the kernel takes, and with fewer waves per workgroup each wave issues more of the tile's staging.  Only short sequences
         // gain (T = 261: 6.9 -> 6.2 us with 64-query blocks).  DINOV2_HIP_ATTN_NWV=2|3|4 forces a size (testing aid; all sizes give
         // the same bits).
-        const char* en = getenv("DINOV2_HIP_ATTN_NWV");
-        int nw = en ? atoi(en) : 0;
+        int nw = tune_get(TUNE_ATTN_NWV);
         if (nw != 2 && nw != 3 && nw != 4) nw = (T <= 512 && (long)((T + 63) / 64) * nh * B <= 256) ? 2 : 4;
         const dim3 grid2(((T + 32 * nw - 1) / (32 * nw)) * nh * B), block2(64 * nw);
 #define DINO_ATT2(TT, LG)                                                                                                        \

@@ -16,7 +16,12 @@
 //     again on the ds_read address: 16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7), which makes every
 //     16-lane ds_read_b128 group hit 16 distinct bank slots.
 //   * 1-D grid with an XCD-aware remap so tiles that share an A row-panel run on the same XCD (shared L2).
+#include <atomic>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <string>
 
 #include "device_types.h"
 #include "kernels.h"
@@ -454,6 +459,14 @@ hipError_t launch_gemm4(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t s
 hipError_t launch_gemm4_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 hipError_t launch_gemm4_short(DType dt, Epilogue epi, const GemmArgs& a, int ni, hipStream_t st);  // 32 ni-row tiles, one per workgroup
 hipError_t gemm4_init();
+#ifdef DINO_WITH_GEMM5
+// tools/probes/gemm5.hip (opt-in build, `make g5`): 192 x 128 tiles on four waves, TWO independent workgroups per CU (one's epilogue under
+// the other's K loop).  Measured slower than the generations above on every GEMM of the forward (profiles/r05_gemm5.md): not in the product.
+bool gemm5_ok(Epilogue epi, const GemmArgs& a);
+int gemm5_wgs_per_cu();
+hipError_t launch_gemm5(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);
+hipError_t gemm5_init();
+#endif
 
 hipError_t gemm_init() {
     hipError_t e = set_attr_cfg<_Float16, 128, 128, 2, 2, 2>();
@@ -474,8 +487,54 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 32, 64, 1, 4, 3, 2>();
     if (e == hipSuccess) e = gemm2_init();
     if (e == hipSuccess) e = gemm4_init();
+#ifdef DINO_WITH_GEMM5
+    if (e == hipSuccess) e = gemm5_init();
+#endif
     return e;
 }
+
+// ---- testing aids, read from the environment ONCE (ADVICE r4 / VERDICT r4 item 7a: they used to be getenv() calls on every launch) -------
+namespace {
+std::atomic<int> g_tune[TUNE_COUNT];
+std::once_flag g_tune_once;
+void tune_init() {
+    static const char* const names[TUNE_COUNT] = {"DINOV2_HIP_GEMM_GEN", "DINOV2_HIP_GEMM_TILE", "DINOV2_HIP_ATTN_V", "DINOV2_HIP_ATTN_NWV"};
+    for (int k = 0; k < TUNE_COUNT; ++k) {
+        const char* e = getenv(names[k]);
+        g_tune[k].store(e ? atoi(e) : 0, std::memory_order_relaxed);
+    }
+}
+}  // namespace
+int tune_get(TuneKey k) {
+    std::call_once(g_tune_once, tune_init);
+    return g_tune[k].load(std::memory_order_relaxed);
+}
+void tune_set(TuneKey k, int v) {
+    std::call_once(g_tune_once, tune_init);
+    g_tune[k].store(v, std::memory_order_relaxed);
+}
+
+// ---- plan recording (gemm_plan_describe): with a sink installed the leaves of launch_gemm note their kernel instead of launching it ------
+namespace {
+thread_local std::string* t_plan_sink = nullptr;
+}
+static bool plan_note(const char* fmt, ...) {
+    if (!t_plan_sink) return false;
+    char buf[128];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (!t_plan_sink->empty()) *t_plan_sink += ';';
+    *t_plan_sink += buf;
+    return true;
+}
+template <typename T, int BM, int BN, int WM, int WN, int NST, int KSUB = 1>
+static hipError_t leaf_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
+    if (plan_note("small<%dx%d,w%dx%d,st%d,ks%d>", BM, BN, WM, WN, NST, KSUB)) return BN / WN == 64 || epi != EPI_SWIGLU ? hipSuccess : hipErrorInvalidValue;
+    return launch_cfg<T, BM, BN, WM, WN, NST, KSUB>(epi, a, st);
+}
+#define DINO_LEAF(CALL, ...) (plan_note(__VA_ARGS__) ? hipSuccess : (CALL))
 
 // Kernel choice: the 256x256 kernel (gemm2.hip) needs N % 256 == 0 (tiles must not straddle q|k|v or a SwiGLU pair,
 // and it has no N edge guards) and enough tiles to fill the 256 CUs; everything else takes the 128x128 kernel here.
@@ -498,19 +557,24 @@ hipError_t gemm_init() {
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     if (a.K % 64 != 0 || a.M <= 0 || a.N <= 0) return hipErrorInvalidValue;
-    // 2-byte outputs larger than the chip's L2s (8 x 4 MiB) leave with non-temporal stores: they would only evict the operand panels, and
-    // their consumer (another kernel) reads them through the memory side; smaller ones (batch 1) are found in L2 by the next kernel
-    if (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU)
-        a.nt_out = (size_t)a.M * (size_t)(epi == EPI_SWIGLU ? a.N / 2 : a.N) * 2 > ((size_t)48 << 20) ? 1 : 0;
+    // 2-byte outputs much larger than the chip's L2s (8 x 4 MiB = 32 MiB) leave with non-temporal stores: they would only evict the operand
+    // panels, and their consumer (another kernel) reads them through the memory side; small ones (batch 1) are found in L2 by the next
+    // kernel.  The threshold, 48 MiB = 1.5 x the L2s, sits between the two regimes that were MEASURED (ViT-L batch 1: outputs <= 11 MB,
+    // ordinary stores win by 3 % of p50; batch 32: outputs >= 90 MB, non-temporal stores win by 0.7 % of the forward -- profiles/r04_gemm4w.md
+    // section 5b); nothing in between was.  Decided ONCE per logical output, at the top-level call: the parts of a split launch (`sub`)
+    // inherit it, so one output never leaves under two store policies.
+    if (!a.sub) {
+        a.nt_out = 0;
+        if (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU)
+            a.nt_out = (size_t)a.M * (size_t)(epi == EPI_SWIGLU ? a.N / 2 : a.N) * 2 > ((size_t)48 << 20) ? 1 : 0;
+    }
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
     // rows are fetched with 16-byte global -> LDS DMA pieces and 16-byte vector loads: strides must keep rows 16-byte aligned
     if (a.lda < 0 || a.ldw < 0 || lda_ % 8 != 0 || ldw_ % 8 != 0 || lda_ < (size_t)a.K || ldw_ < (size_t)a.K) return hipErrorInvalidValue;
     if ((size_t)a.M * lda_ * 2 >= ((size_t)1 << 32) || (size_t)a.N * ldw_ * 2 >= ((size_t)1 << 32)) return hipErrorInvalidValue;
-    static const int forced = [] {
-        const char* e = getenv("DINOV2_HIP_GEMM_TILE");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = tune_get(TUNE_GEMM_TILE);
+    const int gen = tune_get(TUNE_GEMM_GEN);
 #ifdef DINO_GEMM_SWEEP  // tuning builds only: DINOV2_HIP_GEMM_CFG=<n> forces one small-tile configuration (f16)
     {
         const char* e = getenv("DINOV2_HIP_GEMM_CFG");
@@ -551,6 +615,14 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         }
     }
 #endif
+#ifdef DINO_WITH_GEMM5
+    // G5 (round 5, opt-in build only): 192 x 128 tiles, two independent workgroups per CU (tools/probes/gemm5.hip), when the launch has at
+    // least one tile per resident workgroup (512): one launch for any M and any N % 128 == 0.  Only when DINOV2_HIP_GEMM_GEN=5 asks for it.
+    {
+        const long t5 = (long)(a.N / 128) * ((a.M + 191) / 192);
+        if (!a.small_only && !forced && gen == 5 && gemm5_ok(epi, a) && t5 >= 512) return DINO_LEAF(launch_gemm5(dt, epi, a, st), "gemm5<192x128>");
+    }
+#endif
     // N not a multiple of 256 (ViT-S: 384, 1 152): the persistent kernel takes the leading multiple of 256 columns, the small-tile
     // kernel the remaining ones (two launches; every kernel gives a row the same bits, so the cut is invisible in the results).
     // Only where the persistent part fills the chip; not for the patch / SwiGLU epilogues (row -> token scatter indexed with N,
@@ -562,6 +634,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
             (long)(n1 / 256) * ((a.M + 191) / 192) >= 192) {
             const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
             GemmArgs a1 = a, a2 = a;
+            a1.sub = a2.sub = 1;
             a1.N = n1;
             a1.qcols = a.qcols < n1 ? a.qcols : n1;
             a2.N = nrem;
@@ -604,6 +677,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
             a2.M = a.M - M1;
             a2.A = (const char*)a.A + (size_t)M1 * lda_ * 2;
             a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
+            a1.sub = a2.sub = 1;
             const long tail192 = (long)ntn * ((a2.M + 191) / 192);
             const double costC = (double)R + rnd(tail192) * 0.79;
             const double costD = (double)R + (double)a2.M * a.N / unit / 0.5 + 0.1;
@@ -622,25 +696,22 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         // gives at most one tile per CU (QKV at ViT-L batch 1: 180 tiles of 96 rows instead of 132 of 128; FFN-in 240 instead of 176),
         // for the 2-byte epilogues (profiles/r04_gemm4w.md section 6).  DINOV2_HIP_GEMM_GEN=2 keeps plan F.
         {
-            const char* ge = getenv("DINOV2_HIP_GEMM_GEN");
             const bool two_byte = epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU;
-            if (two_byte && !forced && !(ge && atoi(ge) == 2) && gemm4_ok(epi, a) && ((ge && atoi(ge) == 4) || a.K >= 1024)) {
+            if (two_byte && !forced && gen != 2 && gemm4_ok(epi, a) && (gen == 4 || a.K >= 1024)) {
                 int ni = 0;
                 for (int c = 2; c <= 4 && !ni; ++c)
                     if ((long)ntn * ((a.M + 32 * c - 1) / (32 * c)) <= 256) ni = c;
                 const long tiles = ni ? (long)ntn * ((a.M + 32 * ni - 1) / (32 * ni)) : 0;
-                if (ni && tiles >= 112) return launch_gemm4_short(dt, epi, a, ni, st);
+                if (ni && tiles >= 112) return DINO_LEAF(launch_gemm4_short(dt, epi, a, ni, st), "gemm4_short<%d>", 32 * ni);
             }
         }
         {
             const long t128r = (long)ntn * ((a.M + 127) / 128);
-            if (!is_patch && !forced && t128r >= 112 && t128r <= 256) return launch_gemm2_128(dt, epi, a, st);
+            if (!is_patch && !forced && t128r >= 112 && t128r <= 256) return DINO_LEAF(launch_gemm2_128(dt, epi, a, st), "gemm2<128>");
         }
         if (is_patch) plan = (plan == 'E' || t192 < 192) ? 'E' : 'B';  // only the 192-row instantiation exists for this epilogue
         // which generation runs the 256-row / mixed plans: gemm4.hip (four waves, hand-ordered K loop) where it applies, unless
         // DINOV2_HIP_GEMM_GEN=2 asks for gemm2.hip (testing aid: the bit-equality tests compare the two)
-        const char* gen_env = getenv("DINOV2_HIP_GEMM_GEN");  // (read per launch: the tests flip it inside one process)
-        const int gen = gen_env ? atoi(gen_env) : 0;
         // default: gemm4.hip wherever it applies (in the model: FFN-out - 4 %, QKV and FFN-in within 0.5 %, attn-out + 2 %; forward + 0.8 %
         // over gemm2.hip everywhere, same box, interleaved runs -- profiles/r04_gemm4w.md)
         // ... for K >= 1 024: with fewer K-tiles per output tile the four-wave kernel's longer epilogue (one wave per SIMD issues it alone)
@@ -650,11 +721,13 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         // of it in flight: 0.131 against 0.133 ms in the model, four interleaved runs).
         const bool g4 = gen != 2 && gemm4_ok(epi, a) && (gen == 4 || (a.K >= 1024 && !(epi == EPI_RESID && a.K < 2048)));
         switch (plan) {
-            case 'A': return g4 ? launch_gemm4(dt, epi, a, st) : launch_gemm2(dt, epi, a, st);
-            case 'B': return launch_gemm2_192(dt, epi, a, st);
-            case 'C': return g4 ? launch_gemm4_mixed(dt, epi, a1, a2, st) : launch_gemm2_mixed(dt, epi, a1, a2, st);
+            case 'A': return g4 ? DINO_LEAF(launch_gemm4(dt, epi, a, st), "gemm4<256>") : DINO_LEAF(launch_gemm2(dt, epi, a, st), "gemm2<256>");
+            case 'B': return DINO_LEAF(launch_gemm2_192(dt, epi, a, st), "gemm2<192>");
+            case 'C':
+                return g4 ? DINO_LEAF(launch_gemm4_mixed(dt, epi, a1, a2, st), "gemm4_mixed<256+192>")
+                          : DINO_LEAF(launch_gemm2_mixed(dt, epi, a1, a2, st), "gemm2_mixed<256+192>");
             case 'D': {
-                const hipError_t e = g4 ? launch_gemm4(dt, epi, a1, st) : launch_gemm2(dt, epi, a1, st);
+                const hipError_t e = g4 ? DINO_LEAF(launch_gemm4(dt, epi, a1, st), "gemm4<256>") : DINO_LEAF(launch_gemm2(dt, epi, a1, st), "gemm2<256>");
                 if (e != hipSuccess) return e;
                 a2.small_only = 1;  // the tail of a split goes straight to the small-tile kernel below
                 return launch_gemm(dt, epi, a2, st);
@@ -681,17 +754,27 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
     // Nothing about the arithmetic changes -- each output's MFMA chain runs over K in the same order in every configuration.
     if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256 && epi != EPI_SWIGLU) {
         const long t6464 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64), t3264 = (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
-        if (t3264 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 32, 64, 1, 4, 3, 2>(epi, a, st) : launch_cfg<__bf16, 32, 64, 1, 4, 3, 2>(epi, a, st);
-        if (t6464 <= 256) return dt == DT_F16 ? launch_cfg<_Float16, 64, 64, 2, 4, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 64, 2, 4, 3, 2>(epi, a, st);
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 4, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 4, 3, 2>(epi, a, st);
+        if (t3264 <= 256) return dt == DT_F16 ? leaf_cfg<_Float16, 32, 64, 1, 4, 3, 2>(epi, a, st) : leaf_cfg<__bf16, 32, 64, 1, 4, 3, 2>(epi, a, st);
+        if (t6464 <= 256) return dt == DT_F16 ? leaf_cfg<_Float16, 64, 64, 2, 4, 3, 2>(epi, a, st) : leaf_cfg<__bf16, 64, 64, 2, 4, 3, 2>(epi, a, st);
+        return dt == DT_F16 ? leaf_cfg<_Float16, 64, 128, 2, 4, 3, 2>(epi, a, st) : leaf_cfg<__bf16, 64, 128, 2, 4, 3, 2>(epi, a, st);
     }
     if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256)  // (SwiGLU pairs columns inside a 64-wide wave tile)
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3, 2>(epi, a, st);
+        return dt == DT_F16 ? leaf_cfg<_Float16, 64, 128, 4, 2, 3, 2>(epi, a, st) : leaf_cfg<__bf16, 64, 128, 4, 2, 3, 2>(epi, a, st);
     if (cfg == 2 && t64 < 256)
-        return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);
-    if (cfg == 1) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
-    if (cfg == 2) return dt == DT_F16 ? launch_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : launch_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
-    return dt == DT_F16 ? launch_cfg<_Float16, 128, 128, 2, 2, 2>(epi, a, st) : launch_cfg<__bf16, 128, 128, 2, 2, 2>(epi, a, st);
+        return dt == DT_F16 ? leaf_cfg<_Float16, 64, 128, 4, 2, 3>(epi, a, st) : leaf_cfg<__bf16, 64, 128, 4, 2, 3>(epi, a, st);
+    if (cfg == 1) return dt == DT_F16 ? leaf_cfg<_Float16, 64, 128, 2, 2, 2>(epi, a, st) : leaf_cfg<__bf16, 64, 128, 2, 2, 2>(epi, a, st);
+    if (cfg == 2) return dt == DT_F16 ? leaf_cfg<_Float16, 64, 128, 2, 2, 3>(epi, a, st) : leaf_cfg<__bf16, 64, 128, 2, 2, 3>(epi, a, st);
+    return dt == DT_F16 ? leaf_cfg<_Float16, 128, 128, 2, 2, 2>(epi, a, st) : leaf_cfg<__bf16, 128, 128, 2, 2, 2>(epi, a, st);
+}
+
+hipError_t gemm_plan_describe(DType dt, Epilogue epi, const GemmArgs& a, char* out, size_t cap) {
+    if (!out || cap == 0) return hipErrorInvalidValue;
+    std::string s;
+    t_plan_sink = &s;
+    const hipError_t e = launch_gemm(dt, epi, a, nullptr);
+    t_plan_sink = nullptr;
+    snprintf(out, cap, "%s", s.c_str());
+    return e;
 }
 
 }  // namespace dinov2

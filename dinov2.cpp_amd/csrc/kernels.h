@@ -33,11 +33,31 @@ struct GemmArgs {
     float qscale;
     int small_only;     // launch_gemm internal: this is the tail of a split launch, use the small-tile kernel
     int nt_out;         // launch_gemm internal: 2-byte outputs leave with non-temporal stores (set when the output is larger than the L2s)
+    int sub;            // launch_gemm internal: one part of a split launch (inherits nt_out from the whole)
+    unsigned* sched;    // only read by the opt-in generation 5 (tools/probes/gemm5.hip): its ticket counters, GEMM_SCHED_BYTES of
+                        // zero-initialised device memory that no concurrently running launch shares; nullptr = a per-device default
 };
 
+constexpr size_t GEMM_SCHED_BYTES = 8 * 32 * sizeof(unsigned);
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);
 // must be called once per device before the first launch_gemm (raises the dynamic-LDS limit)
 hipError_t gemm_init();
+// Which kernel(s) launch_gemm would run for this problem, without launching anything: a ';'-separated list of kernel plans, e.g.
+// "gemm4_mixed<256+192>" or "gemm4<256>;small<64x128,w2x2,st3,ks1>" (pointers in `a` are not dereferenced).  Returns hipErrorInvalidValue
+// for shapes launch_gemm refuses.  The CPU-side coverage test enumerates the model shapes with it (tests/test_gemm_plans.py).
+hipError_t gemm_plan_describe(DType dt, Epilogue epi, const GemmArgs& a, char* out, size_t cap);
+
+// Testing aids that used to be read from the environment on every launch: read ONCE (first use), changed afterwards only through
+// tune_set (dinov2_hip_op_set_tuning, include/dinov2_hip_ops.h).  0 = the library's own choice.
+enum TuneKey : int {
+    TUNE_GEMM_GEN = 0,   // DINOV2_HIP_GEMM_GEN: 2 | 4 | 5 = force that generation of the persistent GEMM wherever it can run
+    TUNE_GEMM_TILE = 1,  // DINOV2_HIP_GEMM_TILE: 128 | 256 (tuning builds: 129 | 192)
+    TUNE_ATTN_V = 2,     // DINOV2_HIP_ATTN_V: 1 .. 4
+    TUNE_ATTN_NWV = 3,   // DINOV2_HIP_ATTN_NWV: 2 | 3 | 4
+    TUNE_COUNT = 4
+};
+int tune_get(TuneKey k);
+void tune_set(TuneKey k, int v);
 
 // y[r, :] = T(((x - mean) * rsqrt(var + eps)) * w + b)     x f32 [rows, H]; one wave per row
 hipError_t launch_layernorm(DType dt, const float* x, const float* w, const float* b, void* y, int rows, int H,

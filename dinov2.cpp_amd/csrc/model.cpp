@@ -630,6 +630,7 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
     {
         Scope sc(s, K_PATCH_GEMM);
         GemmArgs a{};
+        a.sched = s->sched;
         a.A = s->col; a.W = m->patch_w; a.bias = m->patch_b; a.out = s->x; a.aux = s->pos;
         a.M = B * d.P; a.N = H; a.K = m->kpe_pad; a.ldo = H; a.P = d.P; a.T = d.T; a.R = R;
         HIP_TRY(launch_gemm(dt, EPI_PATCH, a, st));
@@ -644,6 +645,8 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_QKV_GEMM);
             GemmArgs a{};
+            a.sched = s->sched;
+        a.sched = s->sched;
             a.A = s->ln; a.W = ly.qkv_w; a.bias = ly.qkv_b; a.out = s->qkv;
             a.M = d.M; a.N = 3 * H; a.K = H; a.ldo = 3 * H; a.qcols = H;
             a.qscale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) (dinov2.cpp:626) x log2(e): softmax runs on exp2
@@ -656,6 +659,8 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_OPROJ_GEMM);
             GemmArgs a{};
+            a.sched = s->sched;
+        a.sched = s->sched;
             a.A = s->att; a.W = ly.o_w; a.bias = ly.o_b; a.out = s->x; a.aux = ly.ls1;
             a.M = d.M; a.N = H; a.K = H; a.ldo = H;
             HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
@@ -667,6 +672,8 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_FC1_GEMM);
             GemmArgs a{};
+            a.sched = s->sched;
+        a.sched = s->sched;
             a.A = s->ln; a.W = ly.fc1_w; a.bias = ly.fc1_b; a.out = s->hid;
             a.M = d.M; a.N = m->hp.swiglu ? 2 * F : F; a.K = H; a.ldo = F;
             HIP_TRY(launch_gemm(dt, m->hp.swiglu ? EPI_SWIGLU : EPI_GELU, a, st));
@@ -674,6 +681,8 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_FC2_GEMM);
             GemmArgs a{};
+            a.sched = s->sched;
+        a.sched = s->sched;
             a.A = s->hid; a.W = ly.fc2_w; a.bias = ly.fc2_b; a.out = s->x; a.aux = ly.ls2;
             a.M = d.M; a.N = H; a.K = F; a.ldo = H;
             HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
@@ -833,6 +842,11 @@ extern "C" int dinov2_hip_session_create(dinov2_hip_model* m, void* stream, dino
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         s->own_stream = true;
     }
+#ifdef DINO_WITH_GEMM5
+    // (opt-in build with tools/probes/gemm5.hip) this session's own tile-ticket counters: sessions run on their own streams and may overlap
+    HIP_TRY(hipMalloc((void**)&s->sched, GEMM_SCHED_BYTES));
+    HIP_TRY(hipMemset(s->sched, 0, GEMM_SCHED_BYTES));
+#endif
     *out = s.release();
     return DINOV2_HIP_OK;
 }
@@ -848,6 +862,7 @@ extern "C" void dinov2_hip_session_free(dinov2_hip_session* s) {
     if (s->ws) (void)hipFree(s->ws);
     if (s->raw) (void)hipFree(s->raw);
     if (s->pca_buf) (void)hipFree(s->pca_buf);
+    if (s->sched) (void)hipFree(s->sched);
     if (s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1184,6 +1199,7 @@ extern "C" int dinov2_hip_pca3(dinov2_hip_session* s, const float* tokens, int32
     }
     HIP_TRY(launch_pca_prepare(tok, d_mean, buf + o_xt, P, H, Ppad, st));
     GemmArgs a{};  // P * C = Xt Xt^T: both operands are the same [H, Ppad] matrix
+    a.sched = s->sched;
     a.A = buf + o_xt; a.W = buf + o_xt; a.out = d_cov; a.M = H; a.N = H; a.K = Ppad; a.ldo = H;
     HIP_TRY(launch_gemm(DT_F16, EPI_PLAIN_F32, a, st));
 

@@ -50,6 +50,7 @@ struct dinov2_hip_session {
     size_t ws_bytes = 0;
     uint8_t* raw = nullptr;  // raw 8-bit images for DINOV2_HIP_U8_BGR_HWC inputs
     size_t raw_bytes = 0;
+    unsigned* sched = nullptr;  // (opt-in build with tools/probes/gemm5.hip only) tile-ticket counters of the two-workgroups-per-CU GEMM; nullptr otherwise
     char* pca_buf = nullptr;  // dinov2_hip_pca3's device scratch, grown on demand
     size_t pca_bytes = 0;
     int last_b = 0, last_h = 0, last_w = 0;  // shape of the last un-split forward (0: none): what dinov2_hip_fetch copies out

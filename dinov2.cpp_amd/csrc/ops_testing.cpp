@@ -246,6 +246,34 @@ extern "C" float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t
     return ms / iters;
 }
 
+// ---- testing aids: the tuning switches (read from the environment once) and the dispatcher's plan for a shape ----
+extern "C" int dinov2_hip_op_set_tuning(const char* key, int32_t value) {
+    static const char* const names[TUNE_COUNT] = {"gemm_gen", "gemm_tile", "attn_v", "attn_nwv"};
+    if (!key) return DINOV2_HIP_ERR_INVALID;
+    for (int k = 0; k < TUNE_COUNT; ++k)
+        if (std::strcmp(key, names[k]) == 0) {
+            tune_set((TuneKey)k, value);
+            return DINOV2_HIP_OK;
+        }
+    return DINOV2_HIP_ERR_INVALID;
+}
+extern "C" int dinov2_hip_op_get_tuning(const char* key) {
+    static const char* const names[TUNE_COUNT] = {"gemm_gen", "gemm_tile", "attn_v", "attn_nwv"};
+    if (!key) return -1;
+    for (int k = 0; k < TUNE_COUNT; ++k)
+        if (std::strcmp(key, names[k]) == 0) return tune_get((TuneKey)k);
+    return -1;
+}
+// no device needed: nothing is launched and no pointer is dereferenced
+extern "C" int dinov2_hip_op_gemm_plan(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, char* out, int32_t cap) {
+    if (!out || cap <= 0 || epilogue < 0 || epilogue > 5) return DINOV2_HIP_ERR_INVALID;
+    GemmArgs a{};
+    a.M = M; a.N = N; a.K = K; a.ldo = epilogue == EPI_SWIGLU ? N / 2 : N;
+    a.P = 1; a.T = 2;
+    a.qcols = N / 3;
+    return gemm_plan_describe(dtype == 1 ? DT_BF16 : DT_F16, (Epilogue)epilogue, a, out, (size_t)cap) == hipSuccess ? DINOV2_HIP_OK : DINOV2_HIP_ERR_INVALID;
+}
+
 namespace dinov2 { void pca_ritz(const double* yprev, const double* ynext, const double* g_parts, int nparts, int H, double* evals, double* comp); }
 // host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3, for the CPU test-suite
 // Effective shader clock under the dominant kernel: cycles and 100 MHz ticks of the last FFN-in GEMM launch (see gemm2.hip).

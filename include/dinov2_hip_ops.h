@@ -49,6 +49,17 @@ int dinov2_hip_op_preprocess_u8(int32_t mode, const uint8_t *bgr, int32_t B, int
  * current device spent in the kernel: cycles / (ticks * 10 ns) = the clock the power-limited part sustained under that load. */
 int dinov2_hip_op_clock_probe(uint64_t *cycles, uint64_t *ticks_100mhz);
 
+/* Testing aids.  The switches the library used to read from the environment on every launch (DINOV2_HIP_GEMM_GEN, DINOV2_HIP_GEMM_TILE,
+ * DINOV2_HIP_ATTN_V, DINOV2_HIP_ATTN_NWV; include/dinov2_hip.h, "Environment") are read ONCE, on first use; a test that wants to flip one
+ * inside a process calls the setter: key = "gemm_gen" | "gemm_tile" | "attn_v" | "attn_nwv", value 0 = the library's own choice.
+ * Not thread-safe against concurrent forwards on other threads in the sense that they may see either value. */
+int dinov2_hip_op_set_tuning(const char *key, int32_t value);
+int dinov2_hip_op_get_tuning(const char *key); /* -1: unknown key */
+
+/* Which kernel plan launch_gemm picks for a shape, as text: ';'-separated leaves such as "gemm4_mixed<256+192>", "gemm2<128>",
+ * "gemm4<256>;small<64x128,w2x2,st3,ks1>", "gemm5<192x128>".  Needs no device (nothing is launched).  0 on success. */
+int dinov2_hip_op_gemm_plan(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, char *out, int32_t cap);
+
 /* host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3.  yprev [H][8] (any full-rank block), gram [8][8] = yprev^T yprev,
  * ynext [H][8] = cov * (yprev R^-1) with gram = R^T R  ->  evals [3] largest Ritz values of cov on span(yprev), comp [3][H] their
  * unit Ritz vectors, each with its largest loading positive (H >= 8) */

@@ -193,7 +193,7 @@ def test_attention_bitwise_repeatable(api):
 
 
 @pytest.mark.parametrize("T", [1374, 257, 65])
-def test_attention_kernels_agree_bit_for_bit(api, monkeypatch, T):
+def test_attention_kernels_agree_bit_for_bit(api, T):
     """The attention kernels (1: 32 queries per wave, 2: software-pipelined for few workgroups, 3: 64 queries per wave, 4:
     software-pipelined with 64 queries per wave and one wave per SIMD) are picked by grid size; an image must not change with the batch it travels in, so all are held to identical bits (same
     summation order, same rescale points).  T = 257 and 65 leave the last wave / the second query block of a wave ragged."""
@@ -203,22 +203,26 @@ def test_attention_kernels_agree_bit_for_bit(api, monkeypatch, T):
     qkv = _round(rng.standard_normal((B * T, 3 * H)).astype(np.float32) * 0.6, F16)
     qkv[T // 2, :H] *= 6.0  # a query with large scores: forces reference-point moves in some tiles
     outs = {}
-    for v in ("1", "2", "3", "4"):
-        monkeypatch.setenv("DINOV2_HIP_ATTN_V", v)
-        out = np.zeros((B * T, H), np.float32)
-        assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
-        outs[v] = out
-    assert np.isfinite(outs["1"]).all()
-    assert np.array_equal(outs["1"], outs["2"])
-    assert np.array_equal(outs["1"], outs["3"])
-    assert np.array_equal(outs["1"], outs["4"])
-    # the pipelined kernel's smaller workgroups (64- and 96-query blocks: what a batch-1 forward picks to fill the chip)
-    monkeypatch.setenv("DINOV2_HIP_ATTN_V", "2")
-    for nwv in ("2", "3", "4"):
-        monkeypatch.setenv("DINOV2_HIP_ATTN_NWV", nwv)
-        out = np.zeros((B * T, H), np.float32)
-        assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
-        assert np.array_equal(outs["1"], out), nwv
+    try:
+        for v in ("1", "2", "3", "4"):
+            api.set_tuning("attn_v", int(v))
+            out = np.zeros((B * T, H), np.float32)
+            assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
+            outs[v] = out
+        assert np.isfinite(outs["1"]).all()
+        assert np.array_equal(outs["1"], outs["2"])
+        assert np.array_equal(outs["1"], outs["3"])
+        assert np.array_equal(outs["1"], outs["4"])
+        # the pipelined kernel's smaller workgroups (64- and 96-query blocks: what a batch-1 forward picks to fill the chip)
+        api.set_tuning("attn_v", 2)
+        for nwv in (2, 3, 4):
+            api.set_tuning("attn_nwv", nwv)
+            out = np.zeros((B * T, H), np.float32)
+            assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
+            assert np.array_equal(outs["1"], out), nwv
+    finally:
+        api.set_tuning("attn_v", 0)
+        api.set_tuning("attn_nwv", 0)
 
 
 def test_attention_online_softmax_rescale(api):
@@ -471,53 +475,248 @@ def test_gemm_random_shapes_all_plans(api, seed):
 
 
 
-@pytest.mark.parametrize("dt", [F16, BF16])
-@pytest.mark.parametrize("epi", [EPI_QKV, EPI_RESID, EPI_GELU, EPI_SWIGLU, EPI_PLAIN])
-def test_gemm_generation_4_equals_generation_2_bit_for_bit(api, dt, epi, monkeypatch):
-    """gemm4.hip (four waves, accumulators in AGPRs, hand-ordered K loop) against gemm2.hip (eight waves, barrier-separated sections) on
-    the SAME plans: plan A (256-row tiles only: 2 panels x 2 column tiles, the last panel ragged), plan C (whole rounds of 256-row tiles +
-    192-row tiles in one launch, ragged last panel) and K / 64 = 4, 6 and 16.  Every output bit must agree (same MFMA, same K order, same
-    epilogue expressions), and the small-tile kernel's rows (M = 100) must be those bits too."""
-    rng = np.random.default_rng(40 + epi + dt)
-    for (M, N, K) in ((500, 512, 256), (17000, 1024, 384), (9300, 2048, 1024)):
-        Nout = N // 2 if epi == EPI_SWIGLU else N
-        X = _round(rng.standard_normal((100, K)), dt)
-        A = np.ascontiguousarray(np.tile(X, ((M + 99) // 100, 1))[:M])
-        W = _round(rng.standard_normal((N, K)) * 0.05, dt)
-        bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
-        x0 = rng.standard_normal((100, Nout)).astype(np.float32) if epi == EPI_RESID else np.zeros((100, Nout), np.float32)
-        x0 = np.ascontiguousarray(np.tile(x0, ((M + 99) // 100, 1))[:M])
-        outs = {}
-        for gen in ("2", "4"):
-            monkeypatch.setenv("DINOV2_HIP_GEMM_GEN", gen)
+def _has_gen5(api):
+    """generation 5 (tools/probes/gemm5.hip) is an opt-in build: DINOV2_HIP_LIB=.../variants/libdinov2_hip_vg5.so (`make -C dinov2.cpp_amd g5`)"""
+    try:
+        api.set_tuning("gemm_gen", 5)
+        return "gemm5" in api.gemm_plan(F16, EPI_PLAIN, 43968, 1024, 1024)
+    finally:
+        api.set_tuning("gemm_gen", 0)
+
+
+def _gen_case(api, rng, dt, epi, M, N, K, gens, expect):
+    """One shape through the listed generations of the persistent GEMM (`expect[gen]` = a kernel name the dispatcher's plan for that
+    generation must contain, so that the comparison provably runs the kernels it claims to -- ADVICE r4); the rows repeat every 100, so
+    the small-tile kernel's rows (M = 100) are the reference bits for every tile position."""
+    Nout = N // 2 if epi == EPI_SWIGLU else N
+    X = _round(rng.standard_normal((100, K)), dt)
+    A = np.ascontiguousarray(np.tile(X, ((M + 99) // 100, 1))[:M])
+    W = _round(rng.standard_normal((N, K)) * 0.05, dt)
+    bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    x0 = rng.standard_normal((100, Nout)).astype(np.float32) if epi == EPI_RESID else np.zeros((100, Nout), np.float32)
+    x0 = np.ascontiguousarray(np.tile(x0, ((M + 99) // 100, 1))[:M])
+    outs = {}
+    try:
+        for gen in gens:
+            api.set_tuning("gemm_gen", gen)
+            plan = api.gemm_plan(dt, epi, M, N, K)
+            assert expect[gen] in plan, (gen, M, N, K, plan)
             out = x0.copy()
             _gemm(api, dt, epi, A, W, bias, aux if epi == EPI_RESID else None, out, M, N, K, Nout, qcols=N // 4, qscale=0.125)
             outs[gen] = out
-        monkeypatch.delenv("DINOV2_HIP_GEMM_GEN")
-        assert np.isfinite(outs["4"]).all()
-        assert np.array_equal(outs["2"], outs["4"]), (M, N, K)
-        small = x0[:100].copy()
-        _gemm(api, dt, epi, X, W, bias, aux if epi == EPI_RESID else None, small, 100, N, K, Nout, qcols=N // 4, qscale=0.125)
-        assert np.array_equal(small, outs["4"][:100]), (M, N, K)
-        assert np.array_equal(small, outs["4"][M - 100 - M % 100:M - M % 100]), (M, N, K)  # the last whole copy: another tile height
+    finally:
+        api.set_tuning("gemm_gen", 0)
+    first = outs[gens[0]]
+    assert np.isfinite(first).all()
+    for gen in gens[1:]:
+        assert np.array_equal(first, outs[gen]), (gen, M, N, K)
+    small = x0[:100].copy()
+    _gemm(api, dt, epi, X, W, bias, aux if epi == EPI_RESID else None, small, 100, N, K, Nout, qcols=N // 4, qscale=0.125)
+    assert np.array_equal(small, first[:100]), (M, N, K)
+    last = M - 100 - M % 100
+    assert np.array_equal(small, first[last:last + 100]), (M, N, K)  # the last whole copy: another tile height / a ragged panel
+    mid = (M // 200) * 100
+    assert np.array_equal(small, first[mid:mid + 100]), (M, N, K)
 
 
-def test_gemm_generation_4_race_screen(api):
-    """Fifty repeats of a multi-round launch of the four-wave kernel (plan C: 256- and 192-row tiles, next tile staged under the last
-    K-tiles and the epilogue) must reproduce the first result bit for bit: a fragment read ahead of its LDS-DMA data, or a buffer
-    re-staged under a reader, shows up as a rare differing tile."""
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("epi", [EPI_QKV, EPI_RESID, EPI_GELU, EPI_SWIGLU, EPI_PLAIN])
+def test_gemm_generation_4_equals_generation_2_bit_for_bit(api, dt, epi):
+    """gemm4.hip (four waves, accumulators in AGPRs, hand-ordered K loop) against gemm2.hip (eight waves, barrier-separated sections) on
+    the SAME plans, each asserted by name through dinov2_hip_op_gemm_plan:
+      * plan A with more tiles than workgroups and a ragged last panel (98 200 x 512: 384 x 2 = 768 tiles of 256 rows: three rounds, the
+        `has_next` cross-tile staging of gemm4.hip, the last panel 152 rows) -- K / 64 = 4;
+      * plan C, two whole rounds of 256-row tiles + a round of 192-row tiles in one launch (gemm4_mixed_kernel, NI = 8 then 6), ragged
+        last panel -- K / 64 = 6;
+      * plan D, one whole round + the small-tile tail -- K / 64 = 16;
+      * at M = 1 374 the short one-tile-per-workgroup launches (NI = 3 at N = 3 072 / 4 096) for the 2-byte epilogues.
+    Every output bit must agree (same MFMA, same K order, same epilogue expressions), and the small-tile kernel's rows (M = 100) must be
+    those bits too."""
+    rng = np.random.default_rng(40 + epi + dt)
+    _gen_case(api, rng, dt, epi, 98200, 512, 256, (2, 4), {2: "gemm2<256>", 4: "gemm4<256>"})
+    assert ";" not in api.gemm_plan(dt, epi, 98200, 512, 256)
+    _gen_case(api, rng, dt, epi, 41100, 1024, 384, (2, 4), {2: "gemm2_mixed<256+192>", 4: "gemm4_mixed<256+192>"})
+    _gen_case(api, rng, dt, epi, 9300, 2048, 1024, (2, 4), {2: "gemm2<256>;small", 4: "gemm4<256>;small"})
+    if epi in (EPI_QKV, EPI_GELU, EPI_SWIGLU):
+        for N in (3072, 4096):
+            _gen_case(api, rng, dt, epi, 1374, N, 1024, (2, 4), {2: "gemm2<128>", 4: "gemm4_short<96>"})
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("epi", [EPI_QKV, EPI_RESID, EPI_GELU, EPI_SWIGLU, EPI_PLAIN])
+def test_gemm_generation_5_equals_generation_4_bit_for_bit(api, dt, epi):
+    """gemm5.hip (192 x 128 tiles, two independent workgroups per CU, tile hand-over through one barrier, epilogue slices inside K-tile
+    buffer 1) against gemm4.hip and the small-tile kernel: several tiles per workgroup with a ragged last panel (M % 192 != 0), K / 64 =
+    4, 6 and 16, N = 512 ... 2 048.  Generation 5 is a parked, opt-in build (profiles/r05_gemm5.md): skipped against the product library."""
+    if not _has_gen5(api):
+        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
+    rng = np.random.default_rng(50 + epi + dt)
+    _gen_case(api, rng, dt, epi, 40100, 512, 256, (4, 5), {4: "gemm4", 5: "gemm5<192x128>"})
+    _gen_case(api, rng, dt, epi, 23000, 1024, 384, (2, 5), {2: "gemm2", 5: "gemm5<192x128>"})
+    _gen_case(api, rng, dt, epi, 9300, 2048, 1024, (4, 5), {4: "gemm4", 5: "gemm5<192x128>"})
+
+
+@pytest.mark.parametrize("gen,M,N,K,name", [(4, 41100, 1024, 1024, "gemm4_mixed<256+192>"), (4, 98200, 512, 256, "gemm4<256>"),
+                                            (5, 23000, 1024, 512, "gemm5<192x128>")])
+def test_gemm_generation_race_screen(api, gen, M, N, K, name):
+    """Fifty repeats of a multi-round launch of the hand-ordered kernels (gemm4.hip: plan C, 256- and 192-row tiles, next tile staged under
+    the last K-tiles and the epilogue; plan A with four rounds; gemm5.hip: two workgroups per CU, tile hand-over) must reproduce the first
+    result bit for bit: a fragment read ahead of its LDS-DMA data, or a buffer re-staged under a reader, shows up as a rare differing
+    tile.  The generation is forced and the plan asserted by name (the round-4 form of this test ran gemm2.hip)."""
+    if gen == 5 and not _has_gen5(api):
+        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
     rng = np.random.default_rng(77)
-    M, N, K = 23000, 1024, 512
     A = _round(rng.standard_normal((M, K)), F16)
     W = _round(rng.standard_normal((N, K)) * 0.05, F16)
     bias = rng.standard_normal(N).astype(np.float32)
-    ref = np.zeros((M, N), np.float32)
-    _gemm(api, F16, EPI_PLAIN, A, W, bias, None, ref, M, N, K, N)
-    exp = (A[:256].astype(np.float64) @ W.astype(np.float64).T + bias)
-    np.testing.assert_allclose(ref[:256], exp, rtol=2e-5, atol=2e-4)
-    np.testing.assert_allclose(ref[-200:], A[-200:].astype(np.float64) @ W.astype(np.float64).T + bias, rtol=2e-5, atol=2e-4)
-    out = np.zeros_like(ref)
-    for _ in range(50):
-        out[:] = 0
-        _gemm(api, F16, EPI_PLAIN, A, W, bias, None, out, M, N, K, N)
-        assert np.array_equal(out, ref)
+    try:
+        api.set_tuning("gemm_gen", gen)
+        assert name in api.gemm_plan(F16, EPI_PLAIN, M, N, K)
+        ref = np.zeros((M, N), np.float32)
+        _gemm(api, F16, EPI_PLAIN, A, W, bias, None, ref, M, N, K, N)
+        exp = (A[:256].astype(np.float64) @ W.astype(np.float64).T + bias)
+        np.testing.assert_allclose(ref[:256], exp, rtol=2e-5, atol=3e-4)
+        np.testing.assert_allclose(ref[-200:], A[-200:].astype(np.float64) @ W.astype(np.float64).T + bias, rtol=2e-5, atol=3e-4)
+        out = np.zeros_like(ref)
+        for _ in range(50 if M < 100000 else 20):
+            out[:] = 0
+            _gemm(api, F16, EPI_PLAIN, A, W, bias, None, out, M, N, K, N)
+            assert np.array_equal(out, ref)
+    finally:
+        api.set_tuning("gemm_gen", 0)
+
+
+# ---- exhaustive sweeps of the activation epilogues (VERDICT r4 item 3) -------------------------------------------------------------------
+def _all_finite_f16():
+    bits = np.concatenate([np.arange(0x0000, 0x7C00, dtype=np.uint16), np.arange(0x8000, 0xFC00, dtype=np.uint16)])
+    return bits.view(np.float16).astype(np.float32)  # 63 488 values, both zeros included
+
+
+def _f16_ulps(a, b):
+    """distance in f16 representable steps between two arrays of f16-valued floats (monotone integer mapping of the bit patterns)"""
+    def key(x):
+        u = np.asarray(x, np.float32).astype(np.float16).view(np.uint16).astype(np.int32)
+        return np.where(u & 0x8000, -(u & 0x7FFF), u)
+    return np.abs(key(a) - key(b))
+
+
+def _record_sweep(name, **vals):
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "activation_sweeps_r05.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        cur = json.load(open(path)) if os.path.exists(path) else {}
+        cur[name] = vals
+        json.dump(cur, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+def _identity_operands(x, dt, N, ncols_x):
+    """A [M, 64], W [N, 64] with A @ W.T == x (exactly, in f32) in the first `ncols_x` columns pattern given by the caller: x is split
+    into parts the compute dtype holds exactly (f16: x itself; bf16: hi + lo, 8 + 3 significant bits), each multiplied by a 1."""
+    M = x.size
+    A = np.zeros((M, 256), np.float32)  # K = 256: four K-tiles, the least the persistent kernels take; all but the first columns zero
+    if dt == F16:
+        A[:, 0] = x
+        nparts = 1
+    else:
+        hi = _round(x, BF16)
+        lo = x - hi
+        assert np.array_equal(_round(lo, BF16), lo)
+        A[:, 0], A[:, 1] = hi, lo
+        nparts = 2
+    return A, nparts
+
+
+_IMPLS = {"small": ("gemm_tile", 128, "small<"), "gemm2": ("gemm_gen", 2, "gemm2<"), "gemm4": ("gemm_gen", 4, "gemm4<"), "gemm5": ("gemm_gen", 5, "gemm5<")}
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("impl", list(_IMPLS))
+def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
+    """EVERY finite f16 value (63 488 of them) through the GELU epilogue with a pre-activation that IS that value (K = 64, one-hot
+    operands, zero bias), against ggml's table semantics restated in float64: table[h] = f16(gelu_tanh(h)) for |h| < 10, 0 for h <= -10,
+    h for h >= 10 (ggml_gelu_f32; /root/reference/dinov2.cpp:567).  The epilogue evaluates the tanh form with v_exp_f32 / v_rcp_f32
+    (1 ulp approximations), so an entry can differ from the exactly rounded table where the exact value lies within that error of an f16
+    rounding boundary: the test COUNTS those entries, bounds them (<= 1 f16 ulp each, a stated fraction of the table) and records the
+    count in gpurun_out/activation_sweeps_r05.json.  All four epilogue implementations (small-tile kernel, gemm2 / gemm4 / gemm5.hip) are
+    swept, each forced and asserted by plan name."""
+    x = _all_finite_f16()
+    N = 256
+    A, nparts = _identity_operands(x, dt, N, N)
+    W = np.zeros((N, 256), np.float32)
+    W[:, :nparts] = 1.0
+    out = np.zeros((x.size, N), np.float32)
+    key, val, name = _IMPLS[impl]
+    if impl == "gemm5" and not _has_gen5(api):
+        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
+    try:
+        api.set_tuning(key, val)
+        plan = api.gemm_plan(dt, EPI_GELU, x.size, N, 256)
+        assert plan.startswith(name), plan
+        _gemm(api, dt, EPI_GELU, A, W, None, None, out, x.size, N, 256, N)
+    finally:
+        api.set_tuning(key, 0)
+    assert (out == out[:, :1]).all()  # every column computed the same function of the same value
+    got = out[:, 0]
+    xd = x.astype(np.float64)
+    g = 0.5 * xd * (1 + np.tanh(0.79788456080286535587989211986876 * xd * (1 + 0.044715 * xd * xd)))
+    table = np.where(xd <= -10, 0.0, np.where(xd >= 10, xd, g)).astype(np.float16).astype(np.float32)
+    # ggml builds its table in f32 (tanhf): the same expression evaluated in float32
+    xf = x.astype(np.float32)
+    gf = (np.float32(0.5) * xf * (np.float32(1) + np.tanh(np.float32(0.79788456080286535587989211986876) * xf * (np.float32(1) + np.float32(0.044715) * xf * xf)))).astype(np.float32)
+    table32 = np.where(xf <= -10, np.float32(0), np.where(xf >= 10, xf, gf)).astype(np.float16).astype(np.float32)
+    exp = _round(table, dt)
+    ulps = _f16_ulps(got, exp) if dt == F16 else np.where(got == exp, 0, 1)
+    nbad = int((got != exp).sum())
+    nbad32 = int((got != _round(table32, dt)).sum())
+    _record_sweep(f"gelu_{'f16' if dt == F16 else 'bf16'}_{impl}", plan=plan, entries=int(x.size), mismatches_vs_f64_table=nbad,
+                  mismatches_vs_f32_table=nbad32, table_f32_vs_f64=int((table != table32).sum()), max_f16_ulps=int(ulps.max()),
+                  worst_inputs=[float(v) for v in x[got != exp][:8]])
+    assert np.isfinite(got).all()
+    assert ulps.max() <= 1, (nbad, x[ulps > 1][:8])
+    assert nbad <= 64, nbad  # <= 0.1 % of the table within one step of the exactly rounded entry (measured: see the JSON)
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("impl", list(_IMPLS))
+def test_swiglu_epilogue_exhaustive_silu(api, dt, impl):
+    """Every finite f16 value through silu(x1) * x2 with x2 == 1 (the SwiGLU epilogue; ggml_silu_f32 = x / (1 + expf(-x)),
+    /root/reference/dinov2.cpp:605): the T-rounded result against float64, at most one output ulp (f16: 2^-11, bf16: 2^-8 relative) anywhere."""
+    x = _all_finite_f16()
+    F = 128
+    A, nparts = _identity_operands(x, dt, 2 * F, F)
+    # interleaved weights_in rows: 32 x1 units, then the 32 x2 units of the same hidden columns
+    W = np.zeros((2 * F, 256), np.float32)
+    bias = np.zeros(2 * F, np.float32)
+    n = np.arange(2 * F)
+    is_x2 = ((n >> 5) & 1) == 1
+    W[~is_x2, :nparts] = 1.0
+    bias[is_x2] = 1.0
+    out = np.zeros((x.size, F), np.float32)
+    key, val, name = _IMPLS[impl]
+    if impl == "gemm5" and not _has_gen5(api):
+        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
+    try:
+        api.set_tuning(key, val)
+        plan = api.gemm_plan(dt, EPI_SWIGLU, x.size, 2 * F, 256)
+        assert plan.startswith(name), plan
+        _gemm(api, dt, EPI_SWIGLU, A, W, bias, None, out, x.size, 2 * F, 256, F)
+    finally:
+        api.set_tuning(key, 0)
+    assert (out == out[:, :1]).all()
+    got = out[:, 0].astype(np.float64)
+    xd = x.astype(np.float64)
+    with np.errstate(over="ignore"):
+        ref = xd / (1 + np.exp(-xd))
+    exp = _round(ref.astype(np.float32), dt).astype(np.float64)
+    rel = 2.0 ** -11 if dt == F16 else 2.0 ** -8
+    err = np.abs(got - ref)
+    tol = rel * np.maximum(np.abs(ref), 2.0 ** -14) + 2.0 ** -24  # one output ulp (f16 subnormal spacing at the bottom)
+    nbad = int((got != exp).sum())
+    _record_sweep(f"silu_{'f16' if dt == F16 else 'bf16'}_{impl}", plan=plan, entries=int(x.size), not_correctly_rounded=nbad,
+                  worst_err_over_ulp=float((err / tol).max()))
+    assert np.isfinite(got).all()
+    assert (err <= tol).all(), x[err > tol][:8]
