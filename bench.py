@@ -13,14 +13,22 @@ no data-path collective; the only collective is the one-time RCCL broadcast of r
 Timing: after the warm-up steps (and at least `--warm-seconds` of them, so that clocks and caches are in their loaded state) the
 script times `--windows` (default 5) windows of EXACTLY `--steps` steps each, every window bracketed by a barrier +
 synchronize on both sides and taken as the MAX over ranks; `value` / `ms_per_step` are the MEDIAN window (`value_min`,
-`value_max`, `window_values` carry the spread), and `effective_clock_ghz` is the shader clock the power-limited part sustained
-inside the dominant kernel during the last window (s_memtime against the 100 MHz s_memrealtime, stamped by workgroup 0 of the
-FFN-in GEMM) -- boxes differ by +-3.5 % in exactly that clock.
+`value_max`, `window_values` carry the spread), and `effective_clock_ghz` is the shader clock the power-limited part sustained during
+the last window: s_memtime against the 100 MHz s_memrealtime, stamped by workgroup 0 of the last launch of each of the five heavy kernel
+kinds (`kernel_clocks_ghz`: QKV / attn-out / FFN-in / FFN-out GEMMs, attention), weighted by each kind's share of the step -- boxes
+differ by several per cent in exactly that clock (`images_per_sec_per_ghz` is the figure to compare across boxes).
 
 `--backend gloo` (or DINOV2_BENCH_BACKEND=gloo) is a DRY RUN of the N > 1 path on however many GPUs are visible: all ranks share
 the visible device(s) and the collectives go through gloo -- same shard logic, weight broadcast, `broadcast_verified`, config-4
 leg with its teardown / reload, early return of ranks != 0 and final barriers as under RCCL.  Its JSON line says
 `"backend": "gloo-dryrun"`: it is a correctness rehearsal, never a scaling number.
+
+`value_host_buffers` (N = 1): the same workload with HOST buffers on both sides of the boundary -- page-locked f32 images in, logits out,
+through `dinov2_hip_group_submit` / `_wait` with two batches in flight from one host thread -- i.e. the timing definition of the
+reference's `inference.cpp:64-68` (wall time around the whole predict call, input upload included); never `value`.
+`--front group` times that front end as the headline instead (one process, N devices behind the C-ABI, `group_broadcast_ms`).
+With N > 1 the line carries `per_rank` (every rank's own window times, in-kernel clock and broadcast time: a straggler is visible) and
+every collective set-up stage runs under a watchdog that names the stage and the rank on stderr and exits non-zero instead of hanging.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel (the FFN-in GEMM + GELU epilogue, 27 % of all
 FLOPs) from HIP events recorded around each of its launches on the session's own stream; `cpu_baseline` times the
@@ -55,6 +63,82 @@ def parity_bound(args) -> float:
     return 2e-3 if args.model == "giant" else 1e-3
 
 
+class Watchdog:
+    """`with wd.stage("name", seconds):` -- if the block is still running after `seconds`, print which stage of which rank is stuck to
+    stderr and exit the process with code 4 (a hung RCCL rendezvous / broadcast then fails the run with a message instead of sitting in
+    the driver's timeout).  One daemon thread, polled twice a second."""
+
+    def __init__(self, rank):
+        import threading
+        self.rank, self.cur, self.lock = rank, None, threading.Lock()
+        t = threading.Thread(target=self._run, daemon=True)
+        t.start()
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self.lock:
+                cur = self.cur
+            if cur and time.perf_counter() > cur[1]:
+                print(f"bench.py watchdog: rank {self.rank} has been in stage '{cur[0]}' for more than {cur[2]:g} s -- giving up "
+                      f"(MASTER_ADDR={os.environ.get('MASTER_ADDR')} MASTER_PORT={os.environ.get('MASTER_PORT')} "
+                      f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')})", file=sys.stderr, flush=True)
+                os._exit(4)
+
+    def stage(self, name, seconds):
+        wd = self
+
+        class _Ctx:
+            def __enter__(self_):
+                with wd.lock:
+                    wd.cur = (name, time.perf_counter() + seconds, seconds)
+
+            def __exit__(self_, *exc):
+                with wd.lock:
+                    wd.cur = None
+                return False
+        return _Ctx()
+
+
+def group_front(api, path, devices, dt, B, S, num_classes, steps, windows, warmup=2):
+    """Throughput through the C-ABI's multi-device front end with HOST buffers on both sides (page-locked f32 images in, logits out):
+    one process, `len(devices)` devices, the global batch of len(devices) * B images split contiguously, two batches in flight from this
+    one host thread (dinov2_hip_group_submit / _wait).  Returns the median window and the group's own facts."""
+    G = len(devices)
+    grp = api.Group(path, devices=list(devices), dtype=dt, classify=True, broadcast=G > 1, streams_per_device=2)
+    try:
+        rng = np.random.default_rng(7)
+        pin = api.pinned_empty((G * B, 3, S, S), np.float32)
+        pin[:B] = rng.standard_normal((B, 3, S, S), dtype=np.float32)
+        for g in range(1, G):
+            pin[g * B:(g + 1) * B] = pin[:B]
+        kw = dict(classify=True, want=("logits",))
+        for _ in range(warmup):
+            out = grp.predict(pin, **kw)
+        if not np.isfinite(out["logits"]).all():
+            raise SystemExit("group front: non-finite logits")
+        win = []
+        for _ in range(windows):
+            q = []
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                if len(q) == 2:
+                    grp.wait(q.pop(0))
+                q.append(grp.submit(pin, **kw))
+            while q:
+                grp.wait(q.pop(0))
+            win.append(time.perf_counter() - t0)
+        med = float(np.median(win))
+        return {"value": round(G * B * steps / med, 2), "unit": "images/sec", "ms_per_step": round(med / steps * 1e3, 3), "steps": steps, "windows": windows,
+                "window_values": [round(G * B * steps / w, 2) for w in win], "devices": list(devices), "global_batch": G * B,
+                "in_flight": 2, "host_buffers": "page-locked f32 [B, 3, S, S] in, f32 logits out",
+                "group_broadcast_ms": round(grp.broadcast_ms, 2) if G > 1 and grp.broadcast_ms >= 0 else None,
+                "definition": "wall time around whole predict calls with the input upload and the result download inside (the reference's "
+                              "inference.cpp:64-68), two batches in flight from one host thread"}
+    finally:
+        grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -73,6 +157,11 @@ def main():
     ap.add_argument("--warm-seconds", type=float, default=1.0, help="minimum wall time of the warm-up before the first window")
     ap.add_argument("--backend", default=os.environ.get("DINOV2_BENCH_BACKEND", "nccl"), choices=["nccl", "gloo"],
                     help="gloo = dry run of the N > 1 path with all ranks on the visible GPU(s) (labelled as such)")
+    ap.add_argument("--front", default="session", choices=["session", "group"],
+                    help="group = time dinov2_hip_group_submit/_wait (one process, --gpus devices, page-locked host buffers in and out) as the headline")
+    ap.add_argument("--devices", default="", help="--front group: comma-separated device ordinals (default 0 .. gpus-1; a 1-GPU box can rehearse with 0,0,0,0)")
+    ap.add_argument("--no-host-buffers", action="store_true", help="N = 1: skip the host-buffer leg (value_host_buffers)")
+    ap.add_argument("--dist-timeout", type=float, default=180.0, help="seconds a collective set-up stage may take before the watchdog exits")
     ap.add_argument("--no-exact", action="store_true", help="skip the exact-arithmetic / ggml-style-mode distances in cpu_baseline")
     args = ap.parse_args()
     args.windows = max(1, args.windows)
@@ -92,6 +181,38 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    wd = Watchdog(rank)
+
+    if args.front == "group":
+        # ---- the C-ABI's own multi-device front end as the headline: ONE process, N devices, host buffers in and out ----
+        if world > 1:
+            raise SystemExit("--front group is one process for all devices: run it without torch.distributed.run")
+        devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+        cfg = pkg.synth.CONFIGS[args.model]
+        path = os.path.join(tempfile.gettempdir(), f"dinov2_{args.model}_r{args.registers}_{args.wtype}_seed42.gguf")
+        if not os.path.exists(path):
+            tmp = path + f".{os.getpid()}.tmp"
+            pkg.synth.write_synthetic_gguf(tmp, args.model, registers=args.registers, num_classes=1000, seed=42, wtype=args.wtype)
+            os.replace(tmp, path)
+        dtg = api.F16 if args.dtype == "f16" else api.BF16
+        with wd.stage("group front (create + weight broadcast + timed windows)", max(600.0, args.dist_timeout)):
+            g = group_front(api, path, devices, dtg, args.batch, args.size, 1000, args.steps, args.windows, warmup=max(2, args.warmup))
+        gflop_img = pkg.synth.flops_per_image(cfg, args.size, args.size, args.registers, 1000) / 1e9
+        out = {"metric": ("images/sec (518x518), ViT-L/14 fp16" if (args.model, args.size, args.dtype) == ("large", 518, "f16") else
+                          f"images/sec ({args.size}x{args.size}), ViT-{args.model[0].upper()}/14 {'fp16' if args.dtype == 'f16' else args.dtype}"),
+               "value": g["value"], "unit": "images/sec", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": g["ms_per_step"], "windows": args.windows, "window_values": g["window_values"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "front": "group",
+               "front_note": "dinov2_hip_group_submit/_wait: one process, one host thread, two batches in flight, page-locked host buffers in "
+                             "and out (PCIe-inclusive: NOT comparable with the device-resident `value` of the default front)",
+               "devices": g["devices"], "group_broadcast_ms": g["group_broadcast_ms"],
+               "config": {"workload": f"dinov2-{args.model} (ViT-{args.model[0].upper()}/14, {args.registers} registers) {args.wtype} GGUF, "
+                                      f"{args.size}x{args.size}, batch={args.batch} per GPU, classify head, random-init weights",
+                          "global_batch": g["global_batch"], "parallelism": f"dp{len(devices)}", "gflop_per_image": round(gflop_img, 1)},
+               "whole_forward_tflops_per_gpu": round(g["value"] / len(devices) * gflop_img / 1e3, 1)}
+        print(json.dumps(out), flush=True)
+        return
+
     dist = None
     dryrun = args.backend == "gloo"
     if dryrun:  # rehearsal: every rank on the GPU(s) this box has
@@ -110,12 +231,16 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            if dryrun:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
-            else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-            dist.barrier()  # forces the communicator (and the banner) now
-            torch.cuda.synchronize()
+            import datetime
+            tmo = datetime.timedelta(seconds=args.dist_timeout)
+            with wd.stage("init_process_group (rendezvous)", args.dist_timeout + 30):
+                if dryrun:
+                    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=tmo)
+                else:
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=tmo)
+            with wd.stage("first barrier (communicator creation over xGMI)", args.dist_timeout + 30):
+                dist.barrier()  # forces the communicator (and the banner) now
+                torch.cuda.synchronize()
         finally:
             try:
                 ctypes.CDLL(None).fflush(None)
@@ -134,7 +259,8 @@ def main():
                                        wtype=args.wtype)
         os.replace(tmp, path)
     if dist is not None:
-        dist.barrier()
+        with wd.stage("barrier behind the synthetic GGUF", args.dist_timeout + 120):
+            dist.barrier()
     dt = api.F16 if args.dtype == "f16" else api.BF16
     t_load = time.perf_counter()
     model = api.Model(path, device=local, dtype=dt, classify=True, skip_tensor_data=(rank != 0))
@@ -143,10 +269,12 @@ def main():
         ptr, nbytes = model.arena()
         arena = torch.as_tensor(D.DevPtr(ptr, nbytes), device=f"cuda:{local}")
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        D.broadcast_weights(dist, arena, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+        with wd.stage("weight-arena broadcast (rank 0 -> all, %.0f MB)" % (nbytes / 1e6), args.dist_timeout):
+            dist.barrier()  # every rank's arena exists: what follows is the broadcast alone
+            t0 = time.perf_counter()
+            D.broadcast_weights(dist, arena, src=0)
+            torch.cuda.synchronize()
+            bcast_ms = (time.perf_counter() - t0) * 1e3
     load_s = time.perf_counter() - t_load
     sess = api.Session(model)
 
@@ -159,7 +287,8 @@ def main():
         torch.cuda.synchronize()
         sess.predict_device(probe.data_ptr(), 1, args.size, args.size, classify=True, layout=api.RGB_CHW, logits_ptr=plog.data_ptr())
         sess.sync()
-        allp = D.gather_rows(dist, torch, plog, world)
+        with wd.stage("all-gather of the probe image's logits", args.dist_timeout):
+            allp = D.gather_rows(dist, torch, plog, world)
         bcast_ok = bool((allp == allp[0:1]).all().item()) and bool(torch.isfinite(allp).all().item())
         # every rank gathered the same rows, so every rank reaches the same verdict and exits together (no rank is left waiting in
         # a later barrier); the max-reduction makes that explicit even if a gather ever became rank-dependent
@@ -199,31 +328,51 @@ def main():
             step()
         sess.sync()
     # `--windows` windows of EXACTLY `--steps` steps, each bracketed by barrier + synchronize and taken as the max over ranks
-    window_s = []
-    for _ in range(args.windows):
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        sess.sync()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+    window_s, own_s = [], []
+    with wd.stage("timed windows", 600.0 + args.dist_timeout):
+        for _ in range(args.windows):
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            sess.sync()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            own_s.append(el)
+            if dist is not None:
+                el = D.max_over_ranks(dist, torch, el, f"cuda:{local}")
+            window_s.append(el)
         if dist is not None:
-            el = D.max_over_ranks(dist, torch, el, f"cuda:{local}")
-        window_s.append(el)
-    if dist is not None:
-        dist.barrier()
+            dist.barrier()
     elapsed = float(np.median(window_s))
-    # the clock the part sustained inside the dominant kernel of the last window (rank 0's device)
-    eff_clock = dom_dev_ms = None
+    # the clock this rank's device sustained inside the LAST launch of each heavy kernel kind of the last window (workgroup 0's s_memtime
+    # against the 100 MHz s_memrealtime): FFN-in alone (`dom_clock`, the roofline's kernel) and all five kinds (`slot_clock`)
+    dom_clock = dom_dev_ms = None
+    slot_clock = {}
     try:
         import ctypes
-        cyc, tk = ctypes.c_uint64(0), ctypes.c_uint64(0)
-        if api.lib().dinov2_hip_op_clock_probe(ctypes.byref(cyc), ctypes.byref(tk)) == 0 and tk.value > 0:
-            eff_clock = round(cyc.value / (tk.value * 10.0), 4)  # cycles per ns
-            dom_dev_ms = tk.value * 1e-5  # what workgroup 0 (persistent: first tile to last) spent inside that launch, device clock
+        buf = (ctypes.c_uint64 * 12)()
+        if api.lib().dinov2_hip_op_clock_slots(buf) == 0:
+            for i, nm in enumerate(("gemm_qkv", "gemm_attn_out", "gemm_ffn_in", "gemm_ffn_out", "attention")):
+                if buf[2 * i + 1] > 0:
+                    slot_clock[nm] = buf[2 * i] / (buf[2 * i + 1] * 10.0)  # cycles per ns
+            if buf[5] > 0:
+                dom_clock = round(buf[4] / (buf[5] * 10.0), 4)
+                dom_dev_ms = buf[5] * 1e-5  # what workgroup 0 (persistent: first tile to last) spent inside that launch, device clock
     except Exception:
-        eff_clock = None
+        dom_clock = None
+    # every rank's own numbers (a straggling GPU or a slow link is invisible in a max over ranks): gathered on all, printed by rank 0
+    per_rank = None
+    if dist is not None:
+        own_med = float(np.median(own_s))
+        mine = torch.tensor([[float(rank), float(local), B * args.steps / own_med, own_med / args.steps * 1e3, float(dom_clock or 0.0),
+                              float(bcast_ms or 0.0), B * args.steps / max(own_s), B * args.steps / min(own_s)]], dtype=torch.float64,
+                            device=f"cuda:{local}")
+        with wd.stage("all-gather of the per-rank numbers", args.dist_timeout):
+            allr = D.gather_rows(dist, torch, mine, world).cpu().numpy()
+        per_rank = [{"rank": int(r[0]), "device": int(r[1]), "images_per_sec": round(float(r[2]), 2), "ms_per_step": round(float(r[3]), 3),
+                     "effective_clock_ghz": round(float(r[4]), 4) or None, "weight_broadcast_ms": round(float(r[5]), 2),
+                     "images_per_sec_min": round(float(r[6]), 2), "images_per_sec_max": round(float(r[7]), 2)} for r in allr]
     if not bool(torch.isfinite(probs).all()):
         raise SystemExit("non-finite probabilities")
 
@@ -245,11 +394,12 @@ def main():
             gptr, gbytes = gm.arena()
             garena = torch.as_tensor(D.DevPtr(gptr, gbytes), device=f"cuda:{local}")
             torch.cuda.synchronize()
-            dist.barrier()
-            t0 = time.perf_counter()
-            D.broadcast_weights(dist, garena, src=0)
-            torch.cuda.synchronize()
-            g_bcast_ms = D.max_over_ranks(dist, torch, (time.perf_counter() - t0) * 1e3, f"cuda:{local}")
+            with wd.stage("config-4 weight-arena broadcast (%.0f MB)" % (gbytes / 1e6), args.dist_timeout + 60):
+                dist.barrier()
+                t0 = time.perf_counter()
+                D.broadcast_weights(dist, garena, src=0)
+                torch.cuda.synchronize()
+                g_bcast_ms = D.max_over_ranks(dist, torch, (time.perf_counter() - t0) * 1e3, f"cuda:{local}")
             gs = api.Session(gm)
             lo, hi = D.shard_range(64, world, rank)
             gB = hi - lo
@@ -326,6 +476,20 @@ def main():
         kernels[name] = k
     dom = "gemm_ffn_in"
     ach = kernels.get(dom, {}).get("tflops", 0.0)
+    # time-weighted shader clock of the step: each heavy kernel kind's in-kernel clock (last launch of the last timed window) weighted by
+    # the time the step spends in that kind (LayerNorm, head, im2col -- memory-bound, 7 % of the step -- carry no stamp and no weight)
+    eff_clock, clk_cover = None, 0.0
+    if slot_clock:
+        wsum = csum = 0.0
+        for nm, c in slot_clock.items():
+            kk = kernels.get(nm)
+            if kk:
+                w = kk["avg_ms"] * kk["launches_per_step"]
+                wsum += w
+                csum += w * c
+        if wsum > 0:
+            eff_clock = round(csum / wsum, 4)
+            clk_cover = round(wsum / (sum(k["avg_ms"] * k["launches_per_step"] for k in kernels.values()) or 1.0), 3)
     # HBM-side bytes per launch of the dominant kernel: rocprofv3 PMC (FETCH_SIZE and WRITE_SIZE in separate passes, KiB,
     # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), collected by tools/hbm_traffic.sh over this same
     # command and committed under profiles/ (a PMC pass cannot run inside the timed process).
@@ -349,6 +513,7 @@ def main():
                 "flops_per_launch": flops_launch[dom], "avg_launch_ms": kernels.get(dom, {}).get("avg_ms"),
                 # cross-check without the two events a profiled launch carries (they add ~ 5 us of gaps per launch; rocprofv3's average
                 # sits between the two): the same kernel's last launch of the timed windows on the device's own 100 MHz clock
+                "in_kernel_clock_ghz": dom_clock,
                 "in_kernel_ms_device_clock": None if not dom_dev_ms else round(dom_dev_ms, 4),
                 "achieved_by_device_clock": None if not dom_dev_ms else round(flops_launch[dom] / (dom_dev_ms * 1e-3) / 1e12, 1),
                 "whole_forward_tflops": round(value / world * gflop_img / 1e3, 1),
@@ -406,6 +571,18 @@ def main():
         torch.cuda.synchronize()
         two_stream = round(B * 5 / (time.perf_counter() - t0), 2)
         del pair
+
+    # ---- the same workload with HOST buffers on both sides of the boundary (never `value`): page-locked f32 images in, logits out, two
+    #      batches in flight through dinov2_hip_group_submit / _wait -- the reference's own timing definition (inference.cpp:64-68 times the
+    #      whole predict call, upload included)
+    host_leg = None
+    if world == 1 and not dryrun and not args.no_host_buffers:
+        try:
+            with wd.stage("host-buffer leg (dinov2_hip_group_*)", 600.0):
+                host_leg = group_front(api, path, [local], dt, B, S, num_classes, steps=max(4, min(args.steps, 10)), windows=3)
+            host_leg["ratio_to_value"] = round(host_leg["value"] / value, 4)
+        except Exception as e:  # a side measurement must not take the headline down
+            host_leg = {"error": repr(e)}
 
     # ---- CPU baseline: the oracle (restatement of the reference graph) on the host cores, bounded sample ----
     cpu = None
@@ -483,7 +660,10 @@ def main():
         "timing": f"median of {args.windows} windows of {args.steps} steps (barrier + synchronize around each, max over ranks), after "
                   f">= {args.warm_seconds:g} s of warm-up",
         "effective_clock_ghz": eff_clock, "nominal_clock_ghz": 2.4,
-        "value_at_nominal_clock_if_clock_bound": None if not eff_clock else round(value * 2.4 / eff_clock, 1),
+        "effective_clock_note": "time-weighted over the five heavy kernel kinds (kernel_clocks_ghz; they cover %s of the step's kernel time); "
+                                "rank 0's device, last launch of each kind in the last timed window" % clk_cover,
+        "kernel_clocks_ghz": {k: round(v, 4) for k, v in slot_clock.items()} or None,
+        "images_per_sec_per_ghz": None if not eff_clock else round(value / world / eff_clock, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"dinov2-{args.model} (ViT-{args.model[0].upper()}/14, {args.registers} registers) "
                                f"{args.wtype} GGUF, {S}x{S}, batch={B} per GPU, classify head, random-init weights",
@@ -495,7 +675,8 @@ def main():
         "two_sessions_images_per_sec": two_stream,
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
-        "broadcast_verified": bcast_ok, "config4": config4,
+        "broadcast_verified": bcast_ok, "config4": config4, "per_rank": per_rank,
+        "value_host_buffers": host_leg,
     }
     if dryrun:
         out["backend"] = "gloo-dryrun"

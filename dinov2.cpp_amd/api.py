@@ -157,6 +157,7 @@ def lib():
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_pca_ritz.argtypes = [vp, vp, vp, i32, vp, vp]
     L.dinov2_hip_op_clock_probe.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.dinov2_hip_op_clock_slots.argtypes = [C.POINTER(C.c_uint64)]
     L.dinov2_hip_op_probe_tr16.argtypes = [C.POINTER(C.c_int16)]
     L.dinov2_hip_op_preprocess_u8.argtypes = [i32, vp, i32, i32, i32, i32, vp]
     L.dinov2_hip_op_gemm_bench.argtypes = [i32] * 6

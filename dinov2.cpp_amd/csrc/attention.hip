@@ -37,6 +37,12 @@
 
 namespace dinov2 {
 
+// Clock probe slot of this file's kernels (device_types.h, "clock probe")
+__device__ unsigned long long g_clk_att[CLK_SLOTS * 3];
+hipError_t attention_clock_probe_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_att), sizeof(unsigned long long) * CLK_SLOTS * 3);
+}
+
 // -DDINO_ATT_PROF: per-phase s_memtime sums (tuning builds only; `make variant V=prof VFLAGS=-DDINO_ATT_PROF`)
 #ifdef DINO_ATT_PROF
 __device__ unsigned long long g_att_prof[32768 * 8];
@@ -125,6 +131,9 @@ static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
     return max3f(max3f(m0, m1, m2), m3, m3);
 }
 
+#ifndef DINO_PREC
+#define DINO_PREC 0  // tuning builds: which operand roundings attention_kernel removes (gemm.hip, "DINO_PREC"); 0 in the product
+#endif
 #ifndef DINO_ATT_ABL
 #define DINO_ATT_ABL 0  // attention2_kernel, timing-only ablations (WRONG results): 1 no exp, 2 no staging, 4 no barrier, 8 no V
                         // reads, 16 no K reads.  The same study of attention_kernel: tools/probes/attention_abl.hip
@@ -150,11 +159,16 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
     constexpr int ROWB = 128;       // bytes per LDS row (64 dims)
     constexpr int TILEB = KT * ROWB;
 
+#if DINO_PREC & 24
+    __shared__ __attribute__((aligned(16))) char smem[2 * 4 * TILEB];  // [buf][K|V] + [buf][K_lo|V_lo] at + 4 TILEB
+#else
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILEB];  // [buf][K|V]
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     DINO_TS_INIT
+    DINO_CLK_BEGIN()
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // 1-D grid, XCD-aware: the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, which would put the query
     // blocks of one (image, head) on 8 different L2s and fetch its K/V from HBM 8 times (measured: 1.6 GB per launch against
@@ -164,7 +178,11 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
     const int nqb = (Ttok + NWV * QW - 1) / (NWV * QW), nhd = H >> 6;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int qb = lid % nqb, h = (lid / nqb) % nhd, b = lid / (nqb * nhd);
+#if DINO_PREC & 25
+    const int H3 = 6 * H;  // (tuning build) every row carries a second word of q | k | v behind the first: [q k v | q_lo k_lo v_lo]
+#else
     const int H3 = 3 * H;
+#endif
     const char* base = (const char*)(qkv + (size_t)b * Ttok * H3);
 
     const int ql = lane & 31, hh = lane >> 5;
@@ -172,12 +190,19 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 
     // Q^T fragments (B operand): lane holds q[qrow][16*ks + 8*hh + 0..7]
     vec8 qf[QB][4];
+#if DINO_PREC & 1
+    vec8 qfl[QB][4];
+#endif
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
         const int qrc = qrow0 + 32 * u < Ttok ? qrow0 + 32 * u : Ttok - 1;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 4; ++ks) {
             qf[u][ks] = *(const vec8*)(base + ((size_t)qrc * H3 + h * 64 + ks * 16 + hh * 8) * 2);
+#if DINO_PREC & 1
+            qfl[u][ks] = *(const vec8*)(base + ((size_t)qrc * H3 + 3 * H + h * 64 + ks * 16 + hh * 8) * 2);
+#endif
+        }
     }
 
     // staging: a wave-instruction covers 8 rows x 128 B; NWV waves x SI instructions = 64 rows, for K and for V.  Per-lane
@@ -209,6 +234,12 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
             stoff[j] += KT * rowb;
             glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);  // uniform base + 32-bit lane offset: scalar-base loads
             glds16(vbase + (off ^ vswz), sV + (j * NWV + wid) * 8 * ROWB);
+#if DINO_PREC & 8
+            glds16(kbase + (size_t)3 * H * 2 + off, sK + 4 * TILEB + (j * NWV + wid) * 8 * ROWB);
+#endif
+#if DINO_PREC & 16
+            glds16(vbase + (size_t)3 * H * 2 + (off ^ vswz), sV + 4 * TILEB + (j * NWV + wid) * 8 * ROWB);
+#endif
         }
     };
 
@@ -278,7 +309,17 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
                 for (int u = 0; u < QB; ++u) {
                     if (ks == 0) s[u][kb] = mfma32_c(kf, qf[u][0], negm[u]);  // D != C: no copy of the 16 -m_run registers per chain
                     else s[u][kb] = E::mfma32(kf, qf[u][ks], s[u][kb]);
+#if DINO_PREC & 1
+                    s[u][kb] = E::mfma32(kf, qfl[u][ks], s[u][kb]);
+#endif
                 }
+#if DINO_PREC & 8
+                {
+                    const vec8 kfl = *(const vec8*)(sK + 4 * TILEB + kaddr[ks] + kb * 32 * ROWB);
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) s[u][kb] = E::mfma32(kfl, qf[u][ks], s[u][kb]);
+                }
+#endif
             }
         }
         DINO_TS(2)
@@ -338,6 +379,13 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
             for (int u = 0; u < QB; ++u)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[u][j] = E::from_f32(s[u][t >> 1][(t & 1) * 8 + j]);
+#if DINO_PREC & 2
+            vec8 pfl[QB];
+#pragma unroll
+            for (int u = 0; u < QB; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pfl[u][j] = E::from_f32(s[u][t >> 1][(t & 1) * 8 + j] - E::to_f32(pf[u][j]));
+#endif
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 vec8 vf;
@@ -353,6 +401,27 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
                 }
 #pragma unroll
                 for (int u = 0; u < QB; ++u) o[u][db] = E::mfma32(vf, pf[u], o[u][db]);
+#if DINO_PREC & 2
+#pragma unroll
+                for (int u = 0; u < QB; ++u) o[u][db] = E::mfma32(vf, pfl[u], o[u][db]);
+#endif
+#if DINO_PREC & 16
+                {
+                    vec8 vfl;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const s16x4 raw = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (DINO_LDS_AS s16x4*)(sV + 4 * TILEB + vaddr[half][db] + t * 16 * ROWB));
+                        const vec4 v4 = __builtin_bit_cast(vec4, raw);
+                        vfl[half * 4 + 0] = v4[0];
+                        vfl[half * 4 + 1] = v4[1];
+                        vfl[half * 4 + 2] = v4[2];
+                        vfl[half * 4 + 3] = v4[3];
+                    }
+#pragma unroll
+                    for (int u = 0; u < QB; ++u) o[u][db] = E::mfma32(vfl, pf[u], o[u][db]);
+                }
+#endif
             }
         }
         __builtin_amdgcn_s_setprio(0);
@@ -362,6 +431,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
     for (int jt = 0; jt + 1 < ntiles; ++jt) tile(jt, std::false_type{});
     tile(ntiles - 1, std::true_type{});
     DINO_TS_FLUSH
+    DINO_CLK_END(g_clk_att, CLK_ATTENTION)
 
     // ---- normalise and store: o[u][db][r] = O[q][d], d = db*32 + (r&3) + 8*(r>>2) + 4*hh ----
 #pragma unroll
@@ -421,6 +491,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 1 : 2) void attention2_kernel(c
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     DINO_TS_INIT
+    DINO_CLK_BEGIN()
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nqb = (Ttok + WGQ - 1) / WGQ, nhd = H >> 6;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);  // all query blocks of a head on one XCD (see attention_kernel)
@@ -806,6 +877,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 1 : 2) void attention2_kernel(c
 
     DINO_TS(6)
     DINO_TS_FLUSH
+    DINO_CLK_END(g_clk_att, CLK_ATTENTION)
 #pragma unroll
     for (int u = 0; u < QB; ++u) {
         // with LSUM every element of lacc is the full row sum (both lane halves included)

@@ -47,6 +47,31 @@ struct Elem<__bf16> {
     static __device__ __forceinline__ float to_f32(__bf16 x) { return (float)x; }
 };
 
+// ---- clock probe (bench.py `effective_clock_ghz`, `kernel_clocks_ghz`).  Thread 0 of workgroup 0 of every launch of the forward's
+// heavy kernels stamps the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at entry and exit; the LAST launch's
+// differences stay in the slot of its kind: shader cycles / wall time = the clock the power-limited part sustained under that kernel's load
+// (1.6 - 2.0 GHz of a nominal 2.4).  Persistent GEMMs: workgroup 0 lives for the whole launch; attention: for its own tile only (the
+// first of ~ 22 waves of workgroups).  Four scalar loads and three stores per launch.  One array per translation unit (no relocatable
+// device code), merged by dinov2_hip_op_clock_slots (ops_testing.cpp): per slot, the unit with the latest end stamp wins.
+enum ClockSlot : int { CLK_QKV = 0, CLK_ATTN_OUT = 1, CLK_FFN_IN = 2, CLK_FFN_OUT = 3, CLK_ATTENTION = 4, CLK_OTHER = 5, CLK_SLOTS = 6 };
+#define DINO_CLK_BEGIN()                                             \
+    const bool ck_on__ = blockIdx.x == 0 && threadIdx.x == 0;        \
+    unsigned long long ck_c0__ = 0, ck_r0__ = 0;                     \
+    if (ck_on__) {                                                   \
+        ck_c0__ = __builtin_readcyclecounter();                      \
+        ck_r0__ = __builtin_amdgcn_s_memrealtime();                  \
+    }
+#define DINO_CLK_END(ARR, SLOT)                                               \
+    if (ck_on__) {                                                            \
+        const unsigned long long ck_r1__ = __builtin_amdgcn_s_memrealtime();  \
+        (ARR)[(SLOT) * 3 + 0] = __builtin_readcyclecounter() - ck_c0__;       \
+        (ARR)[(SLOT) * 3 + 1] = ck_r1__ - ck_r0__;                            \
+        (ARR)[(SLOT) * 3 + 2] = ck_r1__;                                      \
+    }
+// which slot a GEMM launch belongs to (EPI: kernels.h Epilogue; the residual epilogue serves attn-out, K = N, and FFN-out, K > N)
+#define DINO_CLK_GEMM_SLOT(EPI, N, K) \
+    ((EPI) == 1 ? CLK_QKV : (EPI) == 2 ? ((K) > (N) ? CLK_FFN_OUT : CLK_ATTN_OUT) : ((EPI) == 3 || (EPI) == 4) ? CLK_FFN_IN : CLK_OTHER)
+
 // 16-byte async global -> LDS copy (global_load_lds_dwordx4): LDS destination = wave-uniform `lds` + lane*16
 static __device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
     __builtin_amdgcn_global_load_lds((const DINO_GLOBAL_AS void*)gsrc, (DINO_LDS_AS void*)lds, 16, 0, 0);

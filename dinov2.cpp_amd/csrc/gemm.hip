@@ -28,6 +28,16 @@
 
 namespace dinov2 {
 
+// -DDINO_PREC=<bits> (tuning builds for profiles/r05_parity_attribution.md; the small-tile kernel only -- run them with the "gemm_tile" = 128
+// and "attn_v" = 1 switches): which roundings of the HIP path are REMOVED, one stage at a time, to attribute its distance to exact arithmetic.
+//   1 / 8 / 16  q / k / v keep a second f16 word (lo = f16(x - f16(x)), columns [3H, 6H) of a 6H-wide qkv row) and attention adds the
+//               cross terms K.Q_lo / K_lo.Q / V_lo.P on the matrix core: q, k, v to ~ 22 bits instead of 11
+//   2           the un-normalised probabilities enter PV as hi + lo f16 words as well (P to ~ 22 bits)
+//   4           GELU table entries from a double-precision tanh instead of v_exp_f32 / v_rcp_f32
+#ifndef DINO_PREC
+#define DINO_PREC 0
+#endif
+
 // KSUB = 64-wide K sub-tiles per LDS stage (1, or 2 for the few-tile shapes of a small batch: their K loop is a serial chain of
 // wait -> barrier -> issue -> read -> MFMA per stage, and a stage twice as deep halves the number of links; same K order).
 // -DDINO_GEMM_SPROF (tuning builds): wall-clock (100 MHz) sums of wave 0 of every workgroup -- [0] set-up and the first stages' issue, [1] counted
@@ -267,6 +277,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                             asm("" : "+v"(vq));
                             o[r] = E::from_f32(vq);
                         }
+#if DINO_PREC & 25
+                        {  // second word of q | k | v: columns [N, 2N) of the (6H-wide) row
+                            typename E::vec4 lo;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                float vq = v[r] * qs;
+                                asm("" : "+v"(vq));
+                                lo[r] = E::from_f32(vq - E::to_f32(o[r]));
+                            }
+                            *(typename E::vec4*)((T*)p.out + (size_t)row * p.ldo + N + col0) = lo;
+                        }
+#endif
                     } else {
                         // two columns per instruction (v_pk_*_f32; v_exp / v_rcp / the conversions per element), exactly as gemm2.hip
                         typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -279,6 +301,13 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                             const f32x2 t = xr * __builtin_elementwise_fma(xr * xr, c1, c2);  // -2 log2(e) u
                             const f32x2 den = f32x2{1.0f, 1.0f} + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
                             f32x2 gl = xr * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+#if DINO_PREC & 4
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const double xd = (double)xr[e];
+                                gl[e] = xd <= -10.0 ? 0.0f : xd >= 10.0 ? xr[e] : (float)(0.5 * xd * (1.0 + tanh(0.79788456080286535587989211986876 * xd * (1.0 + 0.044715 * xd * xd))));
+                            }
+#endif
                             asm("" : "+v"(gl));
                             o[2 * e2] = E::from_f32((float)(_Float16)gl[0]);
                             o[2 * e2 + 1] = E::from_f32((float)(_Float16)gl[1]);
@@ -346,6 +375,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                             float vq = v[r] * auxv[r];
                             asm("" : "+v"(vq));
                             o[r] = E::from_f32(vq);
+#if DINO_PREC & 25
+                            if (col0 + r < N) ((T*)p.out)[(size_t)row * p.ldo + N + col0 + r] = E::from_f32(vq - E::to_f32(o[r]));
+#endif
                         } else {
                             // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))).  EXACTLY the expression of
                             // gemm2.hip (same constants, same operation order; the x <= -10 / x >= 10 branches fall out of it):
@@ -353,6 +385,12 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                             const float xr = (float)(_Float16)v[r];
                             const float t = xr * __builtin_fmaf(xr * xr, -0.1029432397f, -2.302208199f);  // -2 log2(e) u
                             float g = xr * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t));
+#if DINO_PREC & 4
+                            {
+                                const double xd = (double)xr;
+                                g = xd <= -10.0 ? 0.0f : xd >= 10.0 ? xr : (float)(0.5 * xd * (1.0 + tanh(0.79788456080286535587989211986876 * xd * (1.0 + 0.044715 * xd * xd))));
+                            }
+#endif
                             asm("" : "+v"(g));
                             o[r] = E::from_f32((float)(_Float16)g);
                         }

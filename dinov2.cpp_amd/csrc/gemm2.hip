@@ -545,36 +545,18 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
     DINO_GP_FLUSH
 }
 
-// Clock probe (bench.py's `effective_clock_ghz`): workgroup 0 of every FFN-in launch (the roofline's dominant kernel) stamps the shader
-// clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at entry and exit; the LAST launch's differences stay in
-// g_clock_probe.  shader cycles / wall time = the clock the part actually sustained under this kernel's load (it is power-limited:
-// 1.6 - 1.9 GHz of a nominal 2.4).  Four scalar loads and one store per launch.
-__device__ unsigned long long g_clock_probe[3];  // cycles, 100 MHz ticks, 100 MHz stamp at the end
-#define DINO_CLOCK_PROBE_BEGIN(EPI)                                                                                   \
-    const bool cp_on__ = ((EPI) == EPI_GELU || (EPI) == EPI_SWIGLU) && blockIdx.x == 0 && threadIdx.x == 0;           \
-    unsigned long long cp_c0__ = 0, cp_r0__ = 0;                                                                      \
-    if (cp_on__) {                                                                                                    \
-        cp_c0__ = __builtin_readcyclecounter();                                                                       \
-        cp_r0__ = __builtin_amdgcn_s_memrealtime();                                                                   \
-    }
-#define DINO_CLOCK_PROBE_END()                                                 \
-    if (cp_on__) {                                                             \
-        const unsigned long long r1__ = __builtin_amdgcn_s_memrealtime();      \
-        g_clock_probe[0] = __builtin_readcyclecounter() - cp_c0__;             \
-        g_clock_probe[1] = r1__ - cp_r0__;                                     \
-        g_clock_probe[2] = r1__;                                               \
-    }
-
-hipError_t gemm_clock_probe_read(unsigned long long out[3]) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe), 3 * sizeof(unsigned long long));
+// Clock probe slots of this file's kernels (device_types.h, "clock probe")
+__device__ unsigned long long g_clk2[CLK_SLOTS * 3];
+hipError_t gemm_clock_probe_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk2), sizeof(unsigned long long) * CLK_SLOTS * 3);
 }
 
 template <typename T, int EPI, int XREP>
 __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DINO_CLOCK_PROBE_BEGIN(EPI)
+    DINO_CLK_BEGIN()
     gemm2_body<T, EPI, XREP>(p, smem);
-    DINO_CLOCK_PROBE_END()
+    DINO_CLK_END(g_clk2, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
 }
 
 // One launch, two tile heights: every block first walks its share of the 256-row tiles of `p` (whole rounds), then its share
@@ -584,10 +566,10 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(512) void gemm2_mixed_kernel(GemmArgs p, GemmArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DINO_CLOCK_PROBE_BEGIN(EPI)
+    DINO_CLK_BEGIN()
     gemm2_body<T, EPI, 4>(p, smem);
     gemm2_body<T, EPI, 3>(q, smem);
-    DINO_CLOCK_PROBE_END()
+    DINO_CLK_END(g_clk2, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
 }
 
 #ifdef DINO_GEMM_PROF

@@ -57,16 +57,17 @@ static __device__ __forceinline__ void static_for(F&& f) {
 #define DINO4_MFMA_BF16(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(W), "v"(X))
 #define DINO4_MFMA_BF16_Z(ACC, W, X) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, 0" : "=a"(ACC) : "v"(W), "v"(X))
 #define DINO4_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
-// (M0 = one wave-uniform base + an immediate: sixteen pieces x two buffers would otherwise sit in thirty-two SGPRs)
+// (M0 = one wave-uniform base + an immediate: sixteen pieces x two buffers would otherwise sit in thirty-two SGPRs.  M0 is a RESERVED
+// register for hipcc: it never keeps a value in it across statements and re-materialises it before each of its own uses (LDS-direct /
+// movrel forms), and it rejects "m0" in a clobber list with -Winline-asm "clobber list contains reserved registers" -- ADVICE r4)
 #define DINO4_GLDS(VOFF, SBASE, LDSBASE, IMM)                                                                                   \
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(LDSBASE), "n"(IMM) \
                  : "memory", "scc")
 
-// Clock probe (bench.py's `effective_clock_ghz`; see gemm2.hip): [0] shader cycles, [1] 100 MHz ticks of workgroup 0 of the last FFN-in
-// launch of THIS file's kernels, [2] the 100 MHz stamp at its end (the reader takes the later of this and gemm2.hip's).
-__device__ unsigned long long g_clock_probe4[3];
-hipError_t gemm4_clock_probe_read(unsigned long long out[3]) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe4), 3 * sizeof(unsigned long long));
+// Clock probe slots of this file's kernels (device_types.h, "clock probe")
+__device__ unsigned long long g_clk4[CLK_SLOTS * 3];
+hipError_t gemm4_clock_probe_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk4), sizeof(unsigned long long) * CLK_SLOTS * 3);
 }
 
 constexpr int G4_PA = 39, G4_PB = 103;  // barrier A / B behind these MFMA indices
@@ -308,6 +309,10 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
               },
               0, has_next, true);
         ktile(T1{}, TF{}, 0, has_next, nop, 1, has_next, has_next);
+        // The compiler's hazard recogniser cannot see into the asm statements: make the last MFMAs' results architecturally visible to the
+        // v_accvgpr_read of the epilogue by hand (16x16x32: 8 passes; the epilogue starts with acc[0][0], written 127 MFMAs ago, but nothing in
+        // the source guarantees that order) -- 24 idle cycles per tile
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
         DINO4_GP(0)
 
         // ---- epilogue (gemm2.hip's, per 64-column group cg of the wave's 128 columns): each wave transposes its result through a private
@@ -489,27 +494,12 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
 #undef DINO4_PIECE
 }
 
-#define DINO4_CLOCK_BEGIN(EPI)                                                                                  \
-    const bool cp_on__ = ((EPI) == EPI_GELU || (EPI) == EPI_SWIGLU) && blockIdx.x == 0 && threadIdx.x == 0;     \
-    unsigned long long cp_c0__ = 0, cp_r0__ = 0;                                                                \
-    if (cp_on__) {                                                                                              \
-        cp_c0__ = __builtin_readcyclecounter();                                                                 \
-        cp_r0__ = __builtin_amdgcn_s_memrealtime();                                                             \
-    }
-#define DINO4_CLOCK_END()                                                    \
-    if (cp_on__) {                                                           \
-        const unsigned long long r1__ = __builtin_amdgcn_s_memrealtime();    \
-        g_clock_probe4[0] = __builtin_readcyclecounter() - cp_c0__;          \
-        g_clock_probe4[1] = r1__ - cp_r0__;                                  \
-        g_clock_probe4[2] = r1__;                                            \
-    }
-
 template <typename T, int EPI, int NI>
 __global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DINO4_CLOCK_BEGIN(EPI)
+    DINO_CLK_BEGIN()
     gemm4_body<T, EPI, NI>(p, smem);
-    DINO4_CLOCK_END()
+    DINO_CLK_END(g_clk4, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
 }
 
 // One launch, two tile heights (gemm2_mixed_kernel's plan): every workgroup first walks its share of the 256-row tiles of `p` (whole
@@ -517,7 +507,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
 template <typename T, int EPI>
 __global__ __launch_bounds__(256) void gemm4_mixed_kernel(GemmArgs p, GemmArgs q) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    DINO4_CLOCK_BEGIN(EPI)
+    DINO_CLK_BEGIN()
 #ifdef DINO_GEMM4_DEPHASE
     // XCDs of odd index take their 192-row tiles FIRST: a quarter of a tile time out of phase with the even ones for the rest of the launch, so
     // that the chip's epilogue bursts (stores, residual read-modify-write) come as two half-size ones.  All workgroups of an XCD stay in step
@@ -531,7 +521,7 @@ __global__ __launch_bounds__(256) void gemm4_mixed_kernel(GemmArgs p, GemmArgs q
         gemm4_body<T, EPI, 8>(p, smem);
         gemm4_body<T, EPI, 6>(q, smem);
     }
-    DINO4_CLOCK_END()
+    DINO_CLK_END(g_clk4, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
 }
 
 constexpr size_t G4_LDS = 163840;

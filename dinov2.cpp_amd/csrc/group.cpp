@@ -445,8 +445,11 @@ extern "C" dinov2_hip_model* dinov2_hip_group_model(dinov2_hip_group* g, int32_t
 
 extern "C" double dinov2_hip_group_broadcast_ms(const dinov2_hip_group* g) { return g ? g->broadcast_ms : -1.0; }
 
-extern "C" int dinov2_hip_group_submit(dinov2_hip_group* g, const dinov2_hip_input* in, const dinov2_hip_output* out, uint32_t flags,
-                                       int64_t* ticket, char* err, size_t errlen) {
+// `require_empty`: refuse (under the SAME hold of g->mu that would enqueue) when another ticket is still un-waited -- the blocking
+// dinov2_hip_group_predict's guard; checking it in one critical section and enqueuing in another let a concurrent submit slip in between
+// and orphan predict's ticket
+static int group_submit_impl(dinov2_hip_group* g, const dinov2_hip_input* in, const dinov2_hip_output* out, uint32_t flags, int64_t* ticket,
+                             bool require_empty, char* err, size_t errlen) {
     if (!g || !in || !in->data || in->batch <= 0 || !ticket) {
         set_err(err, errlen, "null group / input / ticket");
         return DINOV2_HIP_ERR_INVALID;
@@ -471,6 +474,13 @@ extern "C" int dinov2_hip_group_submit(dinov2_hip_group* g, const dinov2_hip_inp
         }
     }
     std::unique_lock<std::mutex> lk(g->mu);
+    if (require_empty && g->submitted != g->retired) {
+        // submit + wait as one unit needs an empty pipeline: with an un-waited ticket ahead of it, the wait would be refused ("in submission
+        // order") AFTER the job had been queued -- a ticket nobody holds, writing into the caller's buffers
+        set_err(err, errlen, "%lld submitted job(s) not waited for yet: dinov2_hip_group_wait them before dinov2_hip_group_predict",
+                (long long)(g->submitted - g->retired));
+        return DINOV2_HIP_ERR_INVALID;
+    }
     if (g->submitted - g->retired >= g->nlanes) {
         set_err(err, errlen, "%d jobs already in flight (streams_per_device): wait for one first", g->nlanes);
         return DINOV2_HIP_ERR_INVALID;
@@ -493,6 +503,11 @@ extern "C" int dinov2_hip_group_submit(dinov2_hip_group* g, const dinov2_hip_inp
     lk.unlock();
     g->cv_job.notify_all();
     return DINOV2_HIP_OK;
+}
+
+extern "C" int dinov2_hip_group_submit(dinov2_hip_group* g, const dinov2_hip_input* in, const dinov2_hip_output* out, uint32_t flags,
+                                       int64_t* ticket, char* err, size_t errlen) {
+    return group_submit_impl(g, in, out, flags, ticket, false, err, errlen);
 }
 
 extern "C" int dinov2_hip_group_wait(dinov2_hip_group* g, int64_t ticket, char* err, size_t errlen) {
@@ -518,18 +533,8 @@ extern "C" int dinov2_hip_group_predict(dinov2_hip_group* g, const dinov2_hip_in
         return DINOV2_HIP_ERR_INVALID;
     }
     std::lock_guard<std::mutex> call(g->call_mu);
-    {
-        // submit + wait as one unit needs an empty pipeline: with an un-waited ticket ahead of it, the wait below would be refused
-        // ("in submission order") AFTER the job had been queued -- a ticket nobody holds, writing into the caller's buffers
-        std::lock_guard<std::mutex> lk(g->mu);
-        if (g->submitted != g->retired) {
-            set_err(err, errlen, "%lld submitted job(s) not waited for yet: dinov2_hip_group_wait them before dinov2_hip_group_predict",
-                    (long long)(g->submitted - g->retired));
-            return DINOV2_HIP_ERR_INVALID;
-        }
-    }
     int64_t t = 0;
-    const int rc = dinov2_hip_group_submit(g, in, out, flags, &t, err, errlen);
+    const int rc = group_submit_impl(g, in, out, flags, &t, true, err, errlen);  // (emptiness check and enqueue under one hold of g->mu)
     if (rc != DINOV2_HIP_OK) return rc;
     return dinov2_hip_group_wait(g, t, err, errlen);
 }

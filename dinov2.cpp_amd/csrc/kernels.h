@@ -142,10 +142,11 @@ hipError_t launch_pca_power(const float* cov, const double* yprev, const double*
 hipError_t launch_pca_project(const float* tok, const float* mean, const float* comp, float* proj, int P, int H,
                               hipStream_t stream);
 
-// shader cycles [0] and 100 MHz ticks [1] of workgroup 0 of the LAST FFN-in GEMM launch of gemm2.hip / gemm4.hip on the current device,
-// [2] the 100 MHz stamp at its end (clock probe)
-hipError_t gemm_clock_probe_read(unsigned long long out[3]);
-hipError_t gemm4_clock_probe_read(unsigned long long out[3]);
+// clock probe (device_types.h): per translation unit, [CLK_SLOTS][3] = shader cycles, 100 MHz ticks, 100 MHz end stamp of workgroup 0 of
+// the LAST launch of each kernel kind on the current device
+hipError_t gemm_clock_probe_read(unsigned long long* out);
+hipError_t gemm4_clock_probe_read(unsigned long long* out);
+hipError_t attention_clock_probe_read(unsigned long long* out);
 
 // debugging aid: what ds_read_b64_tr_b16 returns per lane for addr = lane*8 over an LDS image holding its own
 // element index (out: [64][4] int16)

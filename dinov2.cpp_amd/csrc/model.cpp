@@ -494,7 +494,11 @@ Carve carve_of(const dinov2_hip_model* m, int B, int h, int w) {
     c.col = put(2 * (size_t)B * d.P * m->kpe_pad);
     c.x = put(sizeof(float) * (size_t)d.M * H);
     c.ln = put(2 * (size_t)d.M * H);
+#if defined(DINO_PREC) && (DINO_PREC & 25)
+    c.qkv = put(2 * (size_t)d.M * 6 * H);  // (tuning build, profiles/r05_parity_attribution.md) second f16 word of q | k | v behind the first
+#else
     c.qkv = put(2 * (size_t)d.M * 3 * H);
+#endif
     c.att = put(2 * (size_t)d.M * H);
     c.hid = put(2 * (size_t)d.M * F);
     c.fin = put(sizeof(float) * (size_t)d.M * H);
@@ -649,6 +653,9 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         a.sched = s->sched;
             a.A = s->ln; a.W = ly.qkv_w; a.bias = ly.qkv_b; a.out = s->qkv;
             a.M = d.M; a.N = 3 * H; a.K = H; a.ldo = 3 * H; a.qcols = H;
+#if defined(DINO_PREC) && (DINO_PREC & 25)
+            a.ldo = 6 * H;
+#endif
             a.qscale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) (dinov2.cpp:626) x log2(e): softmax runs on exp2
             HIP_TRY(launch_gemm(dt, EPI_QKV, a, st));
         }

@@ -11,6 +11,7 @@
 
 #include "../../include/dinov2_hip.h"
 #include "../../include/dinov2_hip_ops.h"
+#include "device_types.h"
 #include "kernels.h"
 
 using namespace dinov2;
@@ -276,15 +277,39 @@ extern "C" int dinov2_hip_op_gemm_plan(int32_t dtype, int32_t epilogue, int32_t 
 
 namespace dinov2 { void pca_ritz(const double* yprev, const double* ynext, const double* g_parts, int nparts, int H, double* evals, double* comp); }
 // host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3, for the CPU test-suite
-// Effective shader clock under the dominant kernel: cycles and 100 MHz ticks of the last FFN-in GEMM launch (see gemm2.hip).
-extern "C" int dinov2_hip_op_clock_probe(uint64_t* cycles, uint64_t* ticks_100mhz) {
-    unsigned long long v[3] = {0, 0, 0}, v4[3] = {0, 0, 0};
-    if (hipDeviceSynchronize() != hipSuccess || dinov2::gemm_clock_probe_read(v) != hipSuccess ||
-        dinov2::gemm4_clock_probe_read(v4) != hipSuccess)
+// Clock probe (csrc/device_types.h): merge the per-translation-unit slot arrays -- per slot, the unit whose stamp is latest ran that kind last.
+static int read_clock_slots(unsigned long long out[CLK_SLOTS][3]) {
+    unsigned long long a[3][CLK_SLOTS * 3] = {};
+    if (hipDeviceSynchronize() != hipSuccess || dinov2::gemm_clock_probe_read(a[0]) != hipSuccess ||
+        dinov2::gemm4_clock_probe_read(a[1]) != hipSuccess || dinov2::attention_clock_probe_read(a[2]) != hipSuccess)
         return DINOV2_HIP_ERR_HIP;
-    const unsigned long long* w = v4[2] > v[2] ? v4 : v;  // whichever generation of the kernel ran the last FFN-in launch
-    if (cycles) *cycles = w[0];
-    if (ticks_100mhz) *ticks_100mhz = w[1];
+    for (int s = 0; s < CLK_SLOTS; ++s) {
+        int best = 0;
+        for (int u = 1; u < 3; ++u)
+            if (a[u][s * 3 + 2] > a[best][s * 3 + 2]) best = u;
+        for (int i = 0; i < 3; ++i) out[s][i] = a[best][s * 3 + i];
+    }
+    return DINOV2_HIP_OK;
+}
+// Effective shader clock under the dominant kernel: cycles and 100 MHz ticks of the last FFN-in GEMM launch.
+extern "C" int dinov2_hip_op_clock_probe(uint64_t* cycles, uint64_t* ticks_100mhz) {
+    unsigned long long v[CLK_SLOTS][3];
+    const int rc = read_clock_slots(v);
+    if (rc != DINOV2_HIP_OK) return rc;
+    if (cycles) *cycles = v[CLK_FFN_IN][0];
+    if (ticks_100mhz) *ticks_100mhz = v[CLK_FFN_IN][1];
+    return DINOV2_HIP_OK;
+}
+// All slots: out[2 * slot] = shader cycles, out[2 * slot + 1] = 100 MHz ticks; slots 0 .. 5 = QKV, attn-out, FFN-in, FFN-out, attention, other GEMM
+extern "C" int dinov2_hip_op_clock_slots(uint64_t* out12) {
+    if (!out12) return DINOV2_HIP_ERR_INVALID;
+    unsigned long long v[CLK_SLOTS][3];
+    const int rc = read_clock_slots(v);
+    if (rc != DINOV2_HIP_OK) return rc;
+    for (int s = 0; s < CLK_SLOTS; ++s) {
+        out12[2 * s] = v[s][0];
+        out12[2 * s + 1] = v[s][1];
+    }
     return DINOV2_HIP_OK;
 }
 

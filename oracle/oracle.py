@@ -221,6 +221,15 @@ class OracleModel:
         return out
 
 
+def gelu_table() -> np.ndarray:
+    """ggml's f16 GELU table (65 536 f16 bit patterns indexed by the input's bit pattern), built the way ggml.c builds it."""
+    out = np.zeros(65536, np.uint16)
+    _lib().oracle_gelu_table.argtypes = [C.c_void_p]
+    _lib().oracle_gelu_table.restype = None
+    _lib().oracle_gelu_table(out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def bgr_hwc_to_rgb_chw(img_hwc: np.ndarray) -> np.ndarray:
     """The repack dino_predict does before upload (dinov2.cpp:914-931): BGR interleaved -> RGB planar."""
     return np.ascontiguousarray(img_hwc[:, :, ::-1].transpose(2, 0, 1), dtype=np.float32)

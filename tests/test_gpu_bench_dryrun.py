@@ -47,6 +47,37 @@ def test_bench_multi_rank_dry_run(n, batch):
     assert c4 and c4["finite"] is True and c4["value"] > 0 and c4["dtype"] == "bf16" and f"= {n} x {64 // n}" in c4["workload"]
     assert c4["weight_broadcast_ms"] > 0 and c4["arena_mb"] > 2000
     assert j["roofline"]["kernel"] == "gemm_ffn_in" and j["roofline"]["achieved"] > 0  # rank 0's post-run legs still ran
+    # the line explains itself: every rank's own rate, step time, in-kernel clock and broadcast time
+    pr = j["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(n)) and all(r["images_per_sec"] > 0 and r["ms_per_step"] > 0 for r in pr)
+    assert all(r["weight_broadcast_ms"] > 0 and 1.0 < r["effective_clock_ghz"] < 2.6 for r in pr)
+    assert all(r["images_per_sec_min"] <= r["images_per_sec"] <= r["images_per_sec_max"] for r in pr)
+    assert max(r["ms_per_step"] for r in pr) <= j["ms_per_step"] * 1.5  # `value` is the max over ranks per window: no rank far beyond it
+    assert j["value_host_buffers"] is None  # (N = 1 only)
+
+
+def test_bench_group_front_eight_entries():
+    """`--front group`: the C-ABI's own multi-device front end (one process, dinov2_hip_group_submit / _wait, page-locked host buffers) as
+    the headline, rehearsed as an 8-entry group on the one visible device with a global batch of 8 x 4."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--front", "group", "--gpus", "8", "--devices", "0,0,0,0,0,0,0,0",
+                        "--batch", "4", "--steps", "3", "--warmup", "1", "--windows", "2"], cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["front"] == "group" and j["n_gpus"] == 8 and j["config"]["global_batch"] == 32 and j["devices"] == [0] * 8
+    assert j["value"] > 0 and len(j["window_values"]) == 2
+    assert "group_broadcast_ms" in j  # (None here: a group of duplicates of ONE device has nothing to broadcast over; > 0 on real peers)
+
+
+def test_bench_watchdog_names_the_stage():
+    """A rendezvous that cannot complete (world size 2, one process) must end with exit code 4 and a message naming the stage and the rank,
+    not hang until the caller's timeout."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dist-timeout", "5", "--steps", "1",
+                        "--no-cpu-baseline", "--no-latency"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "init_process_group" in r.stderr or "watchdog" in r.stderr, r.stderr[-2000:]
 
 
 def test_bench_single_rank_line_has_spread_and_clock():
@@ -58,3 +89,8 @@ def test_bench_single_rank_line_has_spread_and_clock():
     assert j["n_gpus"] == 1 and "backend" not in j and j["windows"] == 3 and len(j["window_values"]) == 3
     assert j["value_min"] <= j["value"] <= j["value_max"] and abs(j["ms_per_step"] * j["value"] / 1e3 - 32) < 0.5
     assert 1.0 < j["effective_clock_ghz"] < 2.6, j["effective_clock_ghz"]
+    assert sorted(j["kernel_clocks_ghz"]) == ["attention", "gemm_attn_out", "gemm_ffn_in", "gemm_ffn_out", "gemm_qkv"]
+    assert all(1.0 < c < 2.6 for c in j["kernel_clocks_ghz"].values()) and "value_at_nominal_clock_if_clock_bound" not in j
+    assert j["images_per_sec_per_ghz"] > 0 and j["per_rank"] is None
+    hb = j["value_host_buffers"]  # host buffers in and out through dinov2_hip_group_submit / _wait, never the headline
+    assert hb and hb["value"] > 0 and 0.5 < hb["ratio_to_value"] < 1.1 and hb["in_flight"] == 2

@@ -640,8 +640,8 @@ def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
     operands, zero bias), against ggml's table semantics restated in float64: table[h] = f16(gelu_tanh(h)) for |h| < 10, 0 for h <= -10,
     h for h >= 10 (ggml_gelu_f32; /root/reference/dinov2.cpp:567).  The epilogue evaluates the tanh form with v_exp_f32 / v_rcp_f32
     (1 ulp approximations), so an entry can differ from the exactly rounded table where the exact value lies within that error of an f16
-    rounding boundary: the test COUNTS those entries, bounds them (<= 1 f16 ulp each, a stated fraction of the table) and records the
-    count in gpurun_out/activation_sweeps_r05.json.  All four epilogue implementations (small-tile kernel, gemm2 / gemm4 / gemm5.hip) are
+    rounding boundary: the test COUNTS those entries, bounds them (<= 1 f16 ulp each) and records the counts in
+    gpurun_out/activation_sweeps_r05.json -- against the correctly rounded table AND against ggml's own f32-built table (the oracle's).  All four epilogue implementations (small-tile kernel, gemm2 / gemm4 / gemm5.hip) are
     swept, each forced and asserted by plan name."""
     x = _all_finite_f16()
     N = 256
@@ -664,20 +664,27 @@ def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
     xd = x.astype(np.float64)
     g = 0.5 * xd * (1 + np.tanh(0.79788456080286535587989211986876 * xd * (1 + 0.044715 * xd * xd)))
     table = np.where(xd <= -10, 0.0, np.where(xd >= 10, xd, g)).astype(np.float16).astype(np.float32)
-    # ggml builds its table in f32 (tanhf): the same expression evaluated in float32
-    xf = x.astype(np.float32)
-    gf = (np.float32(0.5) * xf * (np.float32(1) + np.tanh(np.float32(0.79788456080286535587989211986876) * xf * (np.float32(1) + np.float32(0.044715) * xf * xf)))).astype(np.float32)
-    table32 = np.where(xf <= -10, np.float32(0), np.where(xf >= 10, xf, gf)).astype(np.float16).astype(np.float32)
+    # ggml builds its table in f32 with the C library's tanhf (ggml.c): the oracle exports exactly that table (oracle_gelu_table).  It is
+    # itself NOT the correctly rounded one: 274 of its 37 376 entries with |h| < 10 differ from f16(gelu_tanh in double) (f32 rounding of
+    # 1 + tanhf(u) and of the products, measured on this image's glibc), so "ggml's table bit for bit" is not a well-defined target across
+    # hosts; the HIP epilogue is held to BOTH: <= 1 f16 ulp from either, a handful of entries off the correctly rounded table.
+    from oracle import oracle as _oracle
+    tab = _oracle.gelu_table().view(np.float16).astype(np.float32)
+    idx = x.astype(np.float16).view(np.uint16)
+    table32 = np.where(xd <= -10, np.float32(0), np.where(xd >= 10, x, tab[idx])).astype(np.float32)
     exp = _round(table, dt)
+    exp32 = _round(table32, dt)
     ulps = _f16_ulps(got, exp) if dt == F16 else np.where(got == exp, 0, 1)
+    ulps32 = _f16_ulps(got, exp32) if dt == F16 else np.where(got == exp32, 0, 1)
     nbad = int((got != exp).sum())
-    nbad32 = int((got != _round(table32, dt)).sum())
+    nbad32 = int((got != exp32).sum())
     _record_sweep(f"gelu_{'f16' if dt == F16 else 'bf16'}_{impl}", plan=plan, entries=int(x.size), mismatches_vs_f64_table=nbad,
-                  mismatches_vs_f32_table=nbad32, table_f32_vs_f64=int((table != table32).sum()), max_f16_ulps=int(ulps.max()),
-                  worst_inputs=[float(v) for v in x[got != exp][:8]])
+                  mismatches_vs_ggml_f32_table=nbad32, ggml_f32_table_vs_f64_table=int((table != table32).sum()), max_f16_ulps_vs_f64_table=int(ulps.max()),
+                  max_f16_ulps_vs_ggml_f32_table=int(ulps32.max()), inputs_off_the_f64_table=[float(v) for v in x[got != exp][:8]])
     assert np.isfinite(got).all()
     assert ulps.max() <= 1, (nbad, x[ulps > 1][:8])
-    assert nbad <= 64, nbad  # <= 0.1 % of the table within one step of the exactly rounded entry (measured: see the JSON)
+    assert nbad <= 8, nbad      # measured: 5 (f16) / 1 (bf16) of 63 488 entries one step off the correctly rounded table
+    assert ulps32.max() <= 2 and nbad32 <= 400, (nbad32, int(ulps32.max()))  # measured: as many as ggml's own table is off the correctly rounded one
 
 
 @pytest.mark.parametrize("dt", [F16, BF16])
@@ -720,3 +727,55 @@ def test_swiglu_epilogue_exhaustive_silu(api, dt, impl):
                   worst_err_over_ulp=float((err / tol).max()))
     assert np.isfinite(got).all()
     assert (err <= tol).all(), x[err > tol][:8]
+
+
+# ---- every kernel plan the model family can reach, held to the small-tile kernel's bits (tests/gemm_plan_cases.py) ----
+from gemm_plan_cases import COVERAGE_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", COVERAGE_CASES, ids=lambda c: "dt%d-epi%d-%dx%dx%d" % c)
+def test_gemm_plan_coverage_case_bits(api, case):
+    """One problem per reachable (kernel, epilogue, dtype) of the dispatcher (the list is generated from the library's own plan query and
+    checked for completeness on the CPU by tests/test_gemm_plans.py).  The launch under the plan the dispatcher picks must agree BIT FOR
+    BIT (a) over the whole output with the same problem forced onto the plain 128 x 128 / 64 x 128 small-tile kernel
+    (dinov2_hip_op_set_tuning("gemm_tile", 128)), and (b) -- the rows repeat every 100 -- with a 100-row launch of the same rows (few-tile
+    plans: 32 x 64 tiles), so that a token's bits depend neither on the plan nor on the batch it travels in."""
+    dt, epi, M, N, K = case
+    rng = np.random.default_rng(M + 3 * N + 7 * K + 11 * epi + dt)
+    Nout = N // 2 if epi == EPI_SWIGLU else N
+    X = _round(rng.standard_normal((100, K)), dt)
+    A = np.ascontiguousarray(np.tile(X, ((M + 99) // 100, 1))[:M])
+    W = _round(rng.standard_normal((N, K)) * 0.05, dt)
+    bias, aux = rng.standard_normal(N).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    kw = dict(qcols=N // 3, qscale=0.125)
+    if epi == EPI_PATCH:
+        P = 1369 if M % 1369 == 0 else 256 if M % 256 == 0 else M
+        B, R = M // P, 4
+        T = P + 1 + R
+        pos = rng.standard_normal((1 + P, N)).astype(np.float32)
+        x0 = rng.standard_normal((B * T, N)).astype(np.float32)
+        kw.update(P=P, T=T, R=R)
+        auxv, ldo = pos, N
+    else:
+        x0 = rng.standard_normal((100, Nout)).astype(np.float32) if epi == EPI_RESID else np.zeros((100, Nout), np.float32)
+        x0 = np.ascontiguousarray(np.tile(x0, ((M + 99) // 100, 1))[:M])
+        auxv, ldo = (aux if epi == EPI_RESID else None), Nout
+    plan = api.gemm_plan(dt, epi, M, N, K)
+    out = x0.copy()
+    _gemm(api, dt, epi, A, W, bias, auxv, out, M, N, K, ldo, **kw)
+    assert np.isfinite(out).all()
+    try:
+        api.set_tuning("gemm_tile", 128)
+        forced_plan = api.gemm_plan(dt, epi, M, N, K)
+        assert forced_plan.startswith("small<"), forced_plan
+        ref = x0.copy()
+        _gemm(api, dt, epi, A, W, bias, auxv, ref, M, N, K, ldo, **kw)
+    finally:
+        api.set_tuning("gemm_tile", 0)
+    assert np.array_equal(out, ref), (plan, forced_plan)
+    if epi != EPI_PATCH and M > 100:
+        small = x0[:100].copy()
+        _gemm(api, dt, epi, X, W, bias, auxv, small, 100, N, K, ldo, **kw)
+        assert np.array_equal(small, out[:100]), (plan, "rows 0..99")
+        last = M - 100 - M % 100
+        assert np.array_equal(small, out[last:last + 100]), (plan, "last whole copy of the rows")

@@ -511,29 +511,10 @@ static __device__ __forceinline__ void gemm5_body(const GemmArgs& p, char* smem)
 #undef DINO5_PIECE
 }
 
-// Clock probe (bench.py's `effective_clock_ghz`; see gemm2.hip): [0] shader cycles, [1] 100 MHz ticks of workgroup 0 of the last FFN-in
-// launch of THIS file's kernel, [2] the 100 MHz stamp at its end.
-__device__ unsigned long long g_clock_probe5[3];
-hipError_t gemm5_clock_probe_read(unsigned long long out[3]) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clock_probe5), 3 * sizeof(unsigned long long));
-}
-
 template <typename T, int EPI>
 __global__ __launch_bounds__(256, 2) void gemm5_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const bool cp_on = (EPI == EPI_GELU || EPI == EPI_SWIGLU) && blockIdx.x == 0 && threadIdx.x == 0;
-    unsigned long long cp_c0 = 0, cp_r0 = 0;
-    if (cp_on) {
-        cp_c0 = __builtin_readcyclecounter();
-        cp_r0 = __builtin_amdgcn_s_memrealtime();
-    }
     gemm5_body<T, EPI>(p, smem);
-    if (cp_on) {
-        const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-        g_clock_probe5[0] = __builtin_readcyclecounter() - cp_c0;
-        g_clock_probe5[1] = r1 - cp_r0;
-        g_clock_probe5[2] = r1;
-    }
 }
 
 #ifdef DINO_GEMM5_PROF
