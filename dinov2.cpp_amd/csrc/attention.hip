@@ -134,6 +134,11 @@ static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
 #ifndef DINO_PREC
 #define DINO_PREC 0  // tuning builds: which operand roundings attention_kernel removes (gemm.hip, "DINO_PREC"); 0 in the product
 #endif
+#ifndef DINO_ATT_LOADER
+#define DINO_ATT_LOADER 0  // attention_kernel, tuning builds (profiles/r05_attention_loader.md): a LOADER wave issues every global_load_lds of the K / V
+                           // ring, the compute waves none.  1: 4 compute + 1 loader, registers capped for four such workgroups per CU (96);
+                           // 3: the same at 128 registers (three workgroups per CU); 2: 3 compute + 1 loader at 128 registers (96-query blocks)
+#endif
 #ifndef DINO_ATT_ABL
 #define DINO_ATT_ABL 0  // attention2_kernel, timing-only ablations (WRONG results): 1 no exp, 2 no staging, 4 no barrier, 8 no V
                         // reads, 16 no K reads.  The same study of attention_kernel: tools/probes/attention_abl.hip
@@ -151,7 +156,12 @@ static __device__ __forceinline__ float max32(const f32x16 (&s)[2]) {
 // half the LDS bytes per MFMA for twice the registers (two waves per SIMD).  Per query the arithmetic is the same instruction
 // sequence in the same order, so QB does not change a single bit of the result.
 template <typename T, bool LOG2, int NWV, int QB = 1>
-__global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void attention_kernel(const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
+#if DINO_ATT_LOADER
+__global__ __launch_bounds__((NWV + 1) * 64, DINO_ATT_LOADER == 1 ? 5 : DINO_ATT_LOADER == 2 ? 4 : 3) void attention_kernel(
+#else
+__global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void attention_kernel(
+#endif
+    const T* __restrict__ qkv, T* __restrict__ out, int Ttok, int H) {
     using E = Elem<T>;
     using vec8 = typename E::vec8;
     using vec4 = typename E::vec4;
@@ -209,14 +219,22 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
     // 32-bit byte offsets from the (image, head) K base, advanced by one tile per step and clamped to the last key (tail rows
     // re-read it and are masked below): 2 VALU per instruction instead of a 64-bit multiply-add chain.
     const int srow = lane >> 3;
+#if DINO_ATT_LOADER
+    constexpr int SI = 8;         // the loader wave (wid == NWV) moves all eight 8-row pieces of K and of V
+    constexpr int SW = 1;         // piece j covers rows 8 j .. 8 j + 7
+    const int swid = 0;
+#else
     constexpr int SI = 8 / NWV;
+    constexpr int SW = NWV;
+    const int swid = wid;
+#endif
     const char* kbase = base + ((size_t)h * 64 + H) * 2;
     const unsigned rowb = (unsigned)H3 * 2u;
     const char* vbase = kbase + (size_t)H * 2;
     unsigned stoff[SI], stmax[SI];
 #pragma unroll
     for (int j = 0; j < SI; ++j) {
-        const int r = (j * NWV + wid) * 8 + srow;
+        const int r = (j * SW + swid) * 8 + srow;
         const unsigned lc = ((lane & 7) ^ ((r >> 1) & 7)) * 16;
         stoff[j] = (unsigned)r * rowb + lc;
         stmax[j] = (unsigned)(Ttok - 1) * rowb + lc;
@@ -224,6 +242,11 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
     // The V tile has its own chunk swizzle (see vaddr below): chunk ^ (((row >> 1) & 1) << 2) instead of K's
     // chunk ^ ((row >> 1) & 7).  Both depend on the lane only (row >> 1 = 4 * (j * NWV + wid) + (lane >> 4)), and the chunk
     // index is bits 6:4 of the source offset, so V's source offset is K's with those bits XORed by a per-lane constant.
+#if DINO_ATT_LOADER
+    unsigned vswzj[SI];  // (row >> 1 = 4 j + (lane >> 4): the piece's parity replaces the wave's)
+#pragma unroll
+    for (int j = 0; j < SI; ++j) vswzj[j] = (unsigned)((((j & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;
+#endif
     const unsigned vswz = (unsigned)((((wid & 1) << 2) | ((lane >> 4) & 3)) ^ (((lane >> 4) & 1) << 2)) << 4;
     auto stage = [&](int buf, int jt) {  // tiles are staged in order: jt only documents which one this call fetches
         char* sK = smem + buf * 2 * TILEB;
@@ -232,6 +255,11 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
         for (int j = 0; j < SI; ++j) {
             const unsigned off = stoff[j] < stmax[j] ? stoff[j] : stmax[j];
             stoff[j] += KT * rowb;
+#if DINO_ATT_LOADER
+            glds16(kbase + off, sK + j * 8 * ROWB);
+            glds16(vbase + (off ^ vswzj[j]), sV + j * 8 * ROWB);
+            continue;
+#endif
             glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);  // uniform base + 32-bit lane offset: scalar-base loads
             glds16(vbase + (off ^ vswz), sV + (j * NWV + wid) * 8 * ROWB);
 #if DINO_PREC & 8
@@ -293,7 +321,9 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
         DINO_TS(0)
         __syncthreads();
         DINO_TS(1)
+#if !DINO_ATT_LOADER
         if (!MASKED) stage((jt + 1) & 1, jt + 1);
+#endif
         if (idle_wave) return;  // a wave whose 32 queries all lie past the last token only helps with staging and barriers
         const char* sK = smem + (jt & 1) * 2 * TILEB;
         const char* sV = sK + TILEB;
@@ -427,7 +457,18 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
         __builtin_amdgcn_s_setprio(0);
         DINO_TS(5)
     };
+#if DINO_ATT_LOADER
+    if (wid == NWV) {  // the loader wave: one tile ahead of the compute waves, the same barriers, nothing else
+        stage(0, 0);
+        for (int jt = 0; jt < ntiles; ++jt) {
+            __syncthreads();
+            if (jt + 1 < ntiles) stage((jt + 1) & 1, jt + 1);
+        }
+        return;
+    }
+#else
     stage(0, 0);
+#endif
     for (int jt = 0; jt + 1 < ntiles; ++jt) tile(jt, std::false_type{});
     tile(ntiles - 1, std::true_type{});
     DINO_TS_FLUSH
@@ -979,9 +1020,16 @@ static hipError_t launch_attention_impl(DType dt, const void* qkv, void* out, in
 #undef DINO_ATT3
         return hipGetLastError();
     }
+#if DINO_ATT_LOADER
+    constexpr int cw = DINO_ATT_LOADER == 2 ? 3 : 4;  // compute waves; one loader wave on top
+    const dim3 grid(((T + cw * 32 - 1) / (cw * 32)) * nh * B), block((cw + 1) * 64);
+#define DINO_ATT(TT, LG, NW) \
+    hipLaunchKernelGGL((attention_kernel<TT, LG, cw>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
+#else
     const dim3 grid(((T + nwv * 32 - 1) / (nwv * 32)) * nh * B), block(nwv * 64);
 #define DINO_ATT(TT, LG, NW) \
     hipLaunchKernelGGL((attention_kernel<TT, LG, NW>), grid, block, 0, st, (const TT*)qkv, (TT*)out, T, H)
+#endif
 #define DINO_ATT_N(TT, LG) { DINO_ATT(TT, LG, 4); }
     if (dt == DT_F16) { if (log2_scores) DINO_ATT_N(_Float16, true) else DINO_ATT_N(_Float16, false) }
     else { if (log2_scores) DINO_ATT_N(__bf16, true) else DINO_ATT_N(__bf16, false) }
