@@ -56,6 +56,21 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def commit_id() -> str:
+    """The commit the measured tree is at: .head_sha (written by tools/gpurun_measure.sh before the snapshot travels to the GPU box, which
+    has no .git) or `git rev-parse` where a repository is present; "+dirty" when uncommitted changes were in the tree."""
+    try:
+        f = os.path.join(ROOT, ".head_sha")
+        if os.path.exists(f):
+            return open(f).read().strip() or "unknown"
+        import subprocess
+        sha = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip()
+        dirty = subprocess.run(["git", "status", "--porcelain", "--untracked-files=no"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip()
+        return (sha + ("+dirty" if dirty else "")) if sha else "unknown"
+    except Exception:
+        return "unknown"
+
+
 def parity_bound(args) -> float:
     """Stated logit tolerance of a bench configuration, relative to max(1, max|logit|)."""
     if args.dtype != "f16" or args.wtype != "f16":
@@ -200,7 +215,7 @@ def main():
         gflop_img = pkg.synth.flops_per_image(cfg, args.size, args.size, args.registers, 1000) / 1e9
         out = {"metric": ("images/sec (518x518), ViT-L/14 fp16" if (args.model, args.size, args.dtype) == ("large", 518, "f16") else
                           f"images/sec ({args.size}x{args.size}), ViT-{args.model[0].upper()}/14 {'fp16' if args.dtype == 'f16' else args.dtype}"),
-               "value": g["value"], "unit": "images/sec", "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
+               "value": g["value"], "unit": "images/sec", "commit": commit_id(), "n_gpus": len(devices), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": g["ms_per_step"], "windows": args.windows, "window_values": g["window_values"], "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "front": "group",
                "front_note": "dinov2_hip_group_submit/_wait: one process, one host thread, two batches in flight, page-locked host buffers in "
@@ -495,7 +510,7 @@ def main():
     # command and committed under profiles/ (a PMC pass cannot run inside the timed process).
     traffic = None
     try:
-        tfile = next(f for f in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+        tfile = next(f for f in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
                      if os.path.exists(os.path.join(ROOT, "profiles", f)))
         tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
         # FFN-in at this shape runs the mixed 256/192-row launch (gemm.hip plan C): one kernel per GEMM -- gemm4.hip's since round 4
@@ -652,7 +667,7 @@ def main():
         # BASELINE.json's metric on its default configuration; other --model / --size / --dtype runs are labelled as what they are
         "metric": ("images/sec (518x518), ViT-L/14 fp16" if (args.model, args.size, args.dtype) == ("large", 518, "f16") else
                    f"images/sec ({args.size}x{args.size}), ViT-{args.model[0].upper()}/14 {'fp16' if args.dtype == 'f16' else args.dtype}"),
-        "value": round(value, 2), "unit": "images/sec",
+        "value": round(value, 2), "unit": "images/sec", "commit": commit_id(),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "windows": args.windows, "value_min": round(world * B * args.steps / max(window_s), 2),
         "value_max": round(world * B * args.steps / min(window_s), 2),

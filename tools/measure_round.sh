@@ -3,8 +3,25 @@
 # rocprofv3 kernel stats of the bench at batch 32, at batch 1 and at batch 1 / 224 x 224, HBM traffic, MFMA utilisation, the other configurations, the
 # README table, the host-buffer path.  Usage: bash tools/measure_round.sh r03   -> gpurun_out/<tag>_measure/  (copy what should be
 # judged into profiles/<tag>_*).
+# Start it through tools/gpurun_measure.sh (which stamps the commit into .head_sha): every JSON carries "commit", every CSV a "# commit" line.
 TAG=${1:-rXX}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; O=gpurun_out/${TAG}_measure; mkdir -p $O
+SHA=$(cat .head_sha 2>/dev/null || echo unknown); echo "commit $SHA"
+stamp_csv() { for f in "$@"; do [ -f "$f" ] && sed -i "1i # commit $SHA (tools/measure_round.sh $TAG)" "$f"; done; }
+stamp_json() { for f in "$@"; do [ -f "$f" ] && python - "$f" "$SHA" <<'PY'
+import json, sys
+p, sha = sys.argv[1], sys.argv[2]
+try:
+    txt = open(p).read().strip()
+    one_line = len(txt.splitlines()) == 1
+    d = json.loads(txt)
+    if isinstance(d, dict) and d.get("commit") in (None, "unknown"):
+        d["commit"] = sha
+        json.dump(d, open(p, "w"), indent=None if one_line else 1)
+except Exception as e:
+    print("stamp_json", p, e, file=sys.stderr)
+PY
+done; }
 timeout 1500 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" $O/pytest.log | tail -1
 timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench.err; cat $O/bench_n1.json
@@ -19,9 +36,15 @@ timeout 1800 bash tools/other_configs.sh; cp gpurun_out/bench_base_b1.json gpuru
 timeout 600 python bench.py --model small --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_small_b32.json 2> $O/bench_small.err
 timeout 900 python tools/readme_table.py > $O/readme_table.log 2>&1; tail -12 $O/readme_table.log; cp gpurun_out/readme_table.json $O/ 2>/dev/null
 timeout 600 python tools/host_path.py > $O/host_path.log 2>&1; tail -12 $O/host_path.log; cp gpurun_out/host_path.json $O/
-cp gpurun_out/parity_r04.json $O/parity.json 2>/dev/null
+cp gpurun_out/parity_r05.json $O/parity.json 2>/dev/null; cp gpurun_out/activation_sweeps_r05.json $O/activation_sweeps.json 2>/dev/null
 # round 4: the N > 1 code path rehearsed on this one GPU (gloo, all ranks on device 0), the GEMM generations interleaved, the power-wall probes
 timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1 --master-port 29777 bench.py --gpus 8 --steps 3 --warmup 1 --windows 2 --warm-seconds 0 --backend gloo --batch 8 --no-cpu-baseline --no-latency > $O/bench_n8_gloo_dryrun.json 2> $O/bench_n8_dryrun.err; tail -c 600 $O/bench_n8_gloo_dryrun.json
 timeout 900 bash tools/ab_gen.sh > $O/ab_gen.txt 2>&1; cat $O/ab_gen.txt
 [ -x tools/probes/mfma_wall.bin ] && timeout 120 tools/probes/mfma_wall.bin > $O/mfma_wall.txt 2>&1
 [ -x tools/probes/gemm4w_prof.bin ] && timeout 200 tools/probes/gemm4w_prof.bin > $O/gemm4w_probe.txt 2>&1
+# round 5: the C-ABI group front as the headline on this one device (and as a 4-entry duplicate-device group), section profiles of the parked generation 5
+timeout 600 python bench.py --front group --gpus 1 --steps 10 --warmup 2 --windows 3 > $O/bench_front_group_n1.json 2> $O/bench_front_group.err; tail -c 400 $O/bench_front_group_n1.json
+timeout 600 python bench.py --front group --gpus 4 --devices 0,0,0,0 --batch 8 --steps 5 --warmup 2 --windows 2 > $O/bench_front_group_dup4.json 2>> $O/bench_front_group.err
+stamp_csv $O/*.csv
+stamp_json $O/*.json
+ls $O
