@@ -14,7 +14,7 @@ Timing: after the warm-up steps (and at least `--warm-seconds` of them, so that 
 script times `--windows` (default 5) windows of EXACTLY `--steps` steps each, every window bracketed by a barrier +
 synchronize on both sides and taken as the MAX over ranks; `value` / `ms_per_step` are the MEDIAN window (`value_min`,
 `value_max`, `window_values` carry the spread), and `effective_clock_ghz` is the shader clock the power-limited part sustained during
-the last window: s_memtime against the 100 MHz s_memrealtime, stamped by workgroup 0 of the last launch of each of the five heavy kernel
+the timed windows: s_memtime against the 100 MHz s_memrealtime, summed by workgroup 0 over EVERY launch of each of the five heavy kernel
 kinds (`kernel_clocks_ghz`: QKV / attn-out / FFN-in / FFN-out GEMMs, attention), weighted by each kind's share of the step -- boxes
 differ by several per cent in exactly that clock (`images_per_sec_per_ghz` is the figure to compare across boxes).
 
@@ -343,6 +343,15 @@ def main():
             step()
         sess.sync()
     # `--windows` windows of EXACTLY `--steps` steps, each bracketed by barrier + synchronize and taken as the max over ranks
+    def read_clock_sums():
+        try:
+            import ctypes
+            buf = (ctypes.c_uint64 * 18)()
+            return list(buf) if api.lib().dinov2_hip_op_clock_slots(buf) == 0 else None
+        except Exception:
+            return None
+
+    clk0 = read_clock_sums()
     window_s, own_s = [], []
     with wd.stage("timed windows", 600.0 + args.dist_timeout):
         for _ in range(args.windows):
@@ -360,22 +369,20 @@ def main():
         if dist is not None:
             dist.barrier()
     elapsed = float(np.median(window_s))
-    # the clock this rank's device sustained inside the LAST launch of each heavy kernel kind of the last window (workgroup 0's s_memtime
-    # against the 100 MHz s_memrealtime): FFN-in alone (`dom_clock`, the roofline's kernel) and all five kinds (`slot_clock`)
+    # the clock this rank's device sustained inside each heavy kernel kind over ALL launches of the timed windows (workgroup 0's s_memtime
+    # against the 100 MHz s_memrealtime, running sums on the device, read before and after): FFN-in alone (`dom_clock`, the roofline's
+    # kernel) and all five kinds (`slot_clock`)
     dom_clock = dom_dev_ms = None
     slot_clock = {}
-    try:
-        import ctypes
-        buf = (ctypes.c_uint64 * 12)()
-        if api.lib().dinov2_hip_op_clock_slots(buf) == 0:
-            for i, nm in enumerate(("gemm_qkv", "gemm_attn_out", "gemm_ffn_in", "gemm_ffn_out", "attention")):
-                if buf[2 * i + 1] > 0:
-                    slot_clock[nm] = buf[2 * i] / (buf[2 * i + 1] * 10.0)  # cycles per ns
-            if buf[5] > 0:
-                dom_clock = round(buf[4] / (buf[5] * 10.0), 4)
-                dom_dev_ms = buf[5] * 1e-5  # what workgroup 0 (persistent: first tile to last) spent inside that launch, device clock
-    except Exception:
-        dom_clock = None
+    clk1 = read_clock_sums()
+    if clk0 and clk1:
+        for i, nm in enumerate(("gemm_qkv", "gemm_attn_out", "gemm_ffn_in", "gemm_ffn_out", "attention")):
+            dc, dk, dn = clk1[3 * i] - clk0[3 * i], clk1[3 * i + 1] - clk0[3 * i + 1], clk1[3 * i + 2] - clk0[3 * i + 2]
+            if dk > 0 and dn > 0:
+                slot_clock[nm] = dc / (dk * 10.0)  # cycles per ns
+                if nm == "gemm_ffn_in":
+                    dom_clock = round(slot_clock[nm], 4)
+                    dom_dev_ms = dk / dn * 1e-5  # what workgroup 0 (persistent: first tile to last) spent inside a launch on average, device clock
     # every rank's own numbers (a straggling GPU or a slow link is invisible in a max over ranks): gathered on all, printed by rank 0
     per_rank = None
     if dist is not None:
@@ -491,7 +498,7 @@ def main():
         kernels[name] = k
     dom = "gemm_ffn_in"
     ach = kernels.get(dom, {}).get("tflops", 0.0)
-    # time-weighted shader clock of the step: each heavy kernel kind's in-kernel clock (last launch of the last timed window) weighted by
+    # time-weighted shader clock of the step: each heavy kernel kind's in-kernel clock (all launches of the timed windows) weighted by
     # the time the step spends in that kind (LayerNorm, head, im2col -- memory-bound, 7 % of the step -- carry no stamp and no weight)
     eff_clock, clk_cover = None, 0.0
     if slot_clock:
@@ -527,7 +534,7 @@ def main():
                                 "algorithmic bytes/launch = %d" % int(2 * M * H + 2 * H * F + 2 * M * F),
                 "flops_per_launch": flops_launch[dom], "avg_launch_ms": kernels.get(dom, {}).get("avg_ms"),
                 # cross-check without the two events a profiled launch carries (they add ~ 5 us of gaps per launch; rocprofv3's average
-                # sits between the two): the same kernel's last launch of the timed windows on the device's own 100 MHz clock
+                # sits between the two): the same kernel's launches of the timed windows, averaged, on the device's own 100 MHz clock
                 "in_kernel_clock_ghz": dom_clock,
                 "in_kernel_ms_device_clock": None if not dom_dev_ms else round(dom_dev_ms, 4),
                 "achieved_by_device_clock": None if not dom_dev_ms else round(flops_launch[dom] / (dom_dev_ms * 1e-3) / 1e12, 1),
@@ -676,7 +683,7 @@ def main():
                   f">= {args.warm_seconds:g} s of warm-up",
         "effective_clock_ghz": eff_clock, "nominal_clock_ghz": 2.4,
         "effective_clock_note": "time-weighted over the five heavy kernel kinds (kernel_clocks_ghz; they cover %s of the step's kernel time); "
-                                "rank 0's device, last launch of each kind in the last timed window" % clk_cover,
+                                "rank 0's device, averaged over every launch of the timed windows" % clk_cover,
         "kernel_clocks_ghz": {k: round(v, 4) for k, v in slot_clock.items()} or None,
         "images_per_sec_per_ghz": None if not eff_clock else round(value / world / eff_clock, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -38,9 +38,9 @@
 namespace dinov2 {
 
 // Clock probe slot of this file's kernels (device_types.h, "clock probe")
-__device__ unsigned long long g_clk_att[CLK_SLOTS * 3];
+__device__ unsigned long long g_clk_att[CLK_SLOTS * 4];
 hipError_t attention_clock_probe_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_att), sizeof(unsigned long long) * CLK_SLOTS * 3);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk_att), sizeof(unsigned long long) * CLK_SLOTS * 4);
 }
 
 // -DDINO_ATT_PROF: per-phase s_memtime sums (tuning builds only; `make variant V=prof VFLAGS=-DDINO_ATT_PROF`)

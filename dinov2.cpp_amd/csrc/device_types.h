@@ -51,7 +51,7 @@ struct Elem<__bf16> {
 // heavy kernels stamps the shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) at entry and exit; the LAST launch's
 // differences stay in the slot of its kind: shader cycles / wall time = the clock the power-limited part sustained under that kernel's load
 // (1.6 - 2.0 GHz of a nominal 2.4).  Persistent GEMMs: workgroup 0 lives for the whole launch; attention: for its own tile only (the
-// first of ~ 22 waves of workgroups).  Four scalar loads and three stores per launch.  One array per translation unit (no relocatable
+// first of ~ 22 waves of workgroups).  Four scalar loads, three loads and four stores per launch.  One array per translation unit (no relocatable
 // device code), merged by dinov2_hip_op_clock_slots (ops_testing.cpp): per slot, the unit with the latest end stamp wins.
 enum ClockSlot : int { CLK_QKV = 0, CLK_ATTN_OUT = 1, CLK_FFN_IN = 2, CLK_FFN_OUT = 3, CLK_ATTENTION = 4, CLK_OTHER = 5, CLK_SLOTS = 6 };
 #define DINO_CLK_BEGIN()                                             \
@@ -64,9 +64,10 @@ enum ClockSlot : int { CLK_QKV = 0, CLK_ATTN_OUT = 1, CLK_FFN_IN = 2, CLK_FFN_OU
 #define DINO_CLK_END(ARR, SLOT)                                               \
     if (ck_on__) {                                                            \
         const unsigned long long ck_r1__ = __builtin_amdgcn_s_memrealtime();  \
-        (ARR)[(SLOT) * 3 + 0] = __builtin_readcyclecounter() - ck_c0__;       \
-        (ARR)[(SLOT) * 3 + 1] = ck_r1__ - ck_r0__;                            \
-        (ARR)[(SLOT) * 3 + 2] = ck_r1__;                                      \
+        (ARR)[(SLOT) * 4 + 0] += __builtin_readcyclecounter() - ck_c0__;      \
+        (ARR)[(SLOT) * 4 + 1] += ck_r1__ - ck_r0__;                           \
+        (ARR)[(SLOT) * 4 + 2] = ck_r1__;                                      \
+        (ARR)[(SLOT) * 4 + 3] += 1;                                           \
     }
 // which slot a GEMM launch belongs to (EPI: kernels.h Epilogue; the residual epilogue serves attn-out, K = N, and FFN-out, K > N)
 #define DINO_CLK_GEMM_SLOT(EPI, N, K) \

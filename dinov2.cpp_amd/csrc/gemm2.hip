@@ -546,9 +546,9 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
 }
 
 // Clock probe slots of this file's kernels (device_types.h, "clock probe")
-__device__ unsigned long long g_clk2[CLK_SLOTS * 3];
+__device__ unsigned long long g_clk2[CLK_SLOTS * 4];
 hipError_t gemm_clock_probe_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk2), sizeof(unsigned long long) * CLK_SLOTS * 3);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk2), sizeof(unsigned long long) * CLK_SLOTS * 4);
 }
 
 template <typename T, int EPI, int XREP>

@@ -65,9 +65,9 @@ static __device__ __forceinline__ void static_for(F&& f) {
                  : "memory", "scc")
 
 // Clock probe slots of this file's kernels (device_types.h, "clock probe")
-__device__ unsigned long long g_clk4[CLK_SLOTS * 3];
+__device__ unsigned long long g_clk4[CLK_SLOTS * 4];
 hipError_t gemm4_clock_probe_read(unsigned long long* out) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk4), sizeof(unsigned long long) * CLK_SLOTS * 3);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_clk4), sizeof(unsigned long long) * CLK_SLOTS * 4);
 }
 
 constexpr int G4_PA = 39, G4_PB = 103;  // barrier A / B behind these MFMA indices

@@ -142,8 +142,8 @@ hipError_t launch_pca_power(const float* cov, const double* yprev, const double*
 hipError_t launch_pca_project(const float* tok, const float* mean, const float* comp, float* proj, int P, int H,
                               hipStream_t stream);
 
-// clock probe (device_types.h): per translation unit, [CLK_SLOTS][3] = shader cycles, 100 MHz ticks, 100 MHz end stamp of workgroup 0 of
-// the LAST launch of each kernel kind on the current device
+// clock probe (device_types.h): per translation unit, [CLK_SLOTS][4] = running sums of shader cycles and 100 MHz ticks of workgroup 0 over
+// all launches of each kernel kind on the current device, the 100 MHz end stamp of the last one, the launch count
 hipError_t gemm_clock_probe_read(unsigned long long* out);
 hipError_t gemm4_clock_probe_read(unsigned long long* out);
 hipError_t attention_clock_probe_read(unsigned long long* out);

@@ -277,38 +277,45 @@ extern "C" int dinov2_hip_op_gemm_plan(int32_t dtype, int32_t epilogue, int32_t 
 
 namespace dinov2 { void pca_ritz(const double* yprev, const double* ynext, const double* g_parts, int nparts, int H, double* evals, double* comp); }
 // host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3, for the CPU test-suite
-// Clock probe (csrc/device_types.h): merge the per-translation-unit slot arrays -- per slot, the unit whose stamp is latest ran that kind last.
-static int read_clock_slots(unsigned long long out[CLK_SLOTS][3]) {
-    unsigned long long a[3][CLK_SLOTS * 3] = {};
+// Clock probe (csrc/device_types.h): the per-translation-unit slot arrays hold running sums; a kernel kind may be served by more than one
+// unit (gemm2.hip / gemm4.hip by shape), so the sums of all units are added.
+static int read_clock_slots(unsigned long long out[CLK_SLOTS][4]) {
+    unsigned long long a[3][CLK_SLOTS * 4] = {};
     if (hipDeviceSynchronize() != hipSuccess || dinov2::gemm_clock_probe_read(a[0]) != hipSuccess ||
         dinov2::gemm4_clock_probe_read(a[1]) != hipSuccess || dinov2::attention_clock_probe_read(a[2]) != hipSuccess)
         return DINOV2_HIP_ERR_HIP;
     for (int s = 0; s < CLK_SLOTS; ++s) {
-        int best = 0;
-        for (int u = 1; u < 3; ++u)
-            if (a[u][s * 3 + 2] > a[best][s * 3 + 2]) best = u;
-        for (int i = 0; i < 3; ++i) out[s][i] = a[best][s * 3 + i];
+        out[s][0] = out[s][1] = out[s][2] = out[s][3] = 0;
+        for (int u = 0; u < 3; ++u) {
+            out[s][0] += a[u][s * 4 + 0];
+            out[s][1] += a[u][s * 4 + 1];
+            out[s][2] = a[u][s * 4 + 2] > out[s][2] ? a[u][s * 4 + 2] : out[s][2];
+            out[s][3] += a[u][s * 4 + 3];
+        }
     }
     return DINOV2_HIP_OK;
 }
-// Effective shader clock under the dominant kernel: cycles and 100 MHz ticks of the last FFN-in GEMM launch.
+// Running sums for the FFN-in GEMM (the roofline's dominant kernel): shader cycles and 100 MHz ticks of workgroup 0 over all its launches so
+// far on the current device; callers take differences over a window.
 extern "C" int dinov2_hip_op_clock_probe(uint64_t* cycles, uint64_t* ticks_100mhz) {
-    unsigned long long v[CLK_SLOTS][3];
+    unsigned long long v[CLK_SLOTS][4];
     const int rc = read_clock_slots(v);
     if (rc != DINOV2_HIP_OK) return rc;
     if (cycles) *cycles = v[CLK_FFN_IN][0];
     if (ticks_100mhz) *ticks_100mhz = v[CLK_FFN_IN][1];
     return DINOV2_HIP_OK;
 }
-// All slots: out[2 * slot] = shader cycles, out[2 * slot + 1] = 100 MHz ticks; slots 0 .. 5 = QKV, attn-out, FFN-in, FFN-out, attention, other GEMM
-extern "C" int dinov2_hip_op_clock_slots(uint64_t* out12) {
-    if (!out12) return DINOV2_HIP_ERR_INVALID;
-    unsigned long long v[CLK_SLOTS][3];
+// All slots: out18[3 s] = shader cycles, out18[3 s + 1] = 100 MHz ticks, out18[3 s + 2] = launches, running sums; slots 0 .. 5 = QKV, attn-out,
+// FFN-in, FFN-out, attention, other GEMM
+extern "C" int dinov2_hip_op_clock_slots(uint64_t* out18) {
+    if (!out18) return DINOV2_HIP_ERR_INVALID;
+    unsigned long long v[CLK_SLOTS][4];
     const int rc = read_clock_slots(v);
     if (rc != DINOV2_HIP_OK) return rc;
     for (int s = 0; s < CLK_SLOTS; ++s) {
-        out12[2 * s] = v[s][0];
-        out12[2 * s + 1] = v[s][1];
+        out18[3 * s] = v[s][0];
+        out18[3 * s + 1] = v[s][1];
+        out18[3 * s + 2] = v[s][3];
     }
     return DINOV2_HIP_OK;
 }

@@ -240,15 +240,19 @@ int dinov2_hip_abi_version(void);
  *                            replay measured no faster on an idle host; it is there for hosts whose launch thread is contended.
  *   DINOV2_HIP_MAX_CHUNK=n   testing aid: split a predict call into passes of at most n images (the split that otherwise only
  *                            happens past 2^31 bytes of activations), to exercise that path at small sizes.
- *   DINOV2_HIP_ATTN_V=1|2|3|4  testing aid: force the throughput / the software-pipelined attention kernel (normally chosen by
- *   DINOV2_HIP_GEMM_TILE=128|256   workgroup count; 3 and 4 = the measured, never auto-selected 64-queries-per-wave variants: two waves
- *                            per SIMD, and software-pipelined with one wave per SIMD) and the small-tile / persistent GEMM (normally
- *                            chosen by shape): the bit-equality tests of the kernels use them.
- *   DINOV2_HIP_ATTN_NWV=2|3|4  testing aid: waves (32-query blocks) per workgroup of the software-pipelined attention kernel (normally 4;
- *                            2 for short sequences); every size gives the same bits.
- *   DINOV2_HIP_GEMM_GEN=2|4  testing aid: which generation of the persistent GEMM runs the 256-row / mixed plans -- 2 = gemm2.hip (eight waves,
- *                            barrier-separated sections), 4 = gemm4.hip (four waves, hand-ordered K loop; the default wherever it applies).
- *                            Both give every row the same bits; read per launch.
+ *   The next four are testing aids that pick a kernel the library would otherwise choose by shape.  They are read ONCE, on first use
+ *   (round 5; they used to be getenv() calls on every launch); a test that flips one inside a process uses dinov2_hip_op_set_tuning
+ *   (include/dinov2_hip_ops.h), and dinov2_hip_op_gemm_plan reports which GEMM kernels a shape gets under the current setting.
+ *   DINOV2_HIP_ATTN_V=1|2|3|4  force the throughput / the software-pipelined attention kernel (normally chosen by workgroup count; 3 and 4 =
+ *                            the measured, never auto-selected 64-queries-per-wave variants: two waves per SIMD, and software-pipelined
+ *                            with one wave per SIMD).  All give the same bits.
+ *   DINOV2_HIP_ATTN_NWV=2|3|4  waves (32-query blocks) per workgroup of the software-pipelined attention kernel (normally 4; 2 for short
+ *                            sequences); every size gives the same bits.
+ *   DINOV2_HIP_GEMM_TILE=128|256   the small-tile kernel only / 256-row persistent tiles only.
+ *   DINOV2_HIP_GEMM_GEN=2|4  which generation of the persistent GEMM runs the 256-row / mixed / one-tile-per-workgroup plans -- 2 = gemm2.hip
+ *                            (eight waves, barrier-separated sections), 4 = gemm4.hip (four waves, hand-ordered K loop; the default for
+ *                            K >= 1 024).  Both give every row the same bits.  (5 = the parked two-workgroups-per-CU generation, only
+ *                            in the opt-in build `make -C dinov2.cpp_amd g5`: profiles/r05_gemm5.md.)
  *   DINOV2_HIP_GROUP_REQUIRE_RCCL=1  dinov2_hip_group_create fails when librccl cannot be loaded instead of letting every device
  *                            read the GGUF itself.
  * (DINOV2_HIP_LIB, read by the Python binding only, points it at another build of this library.) */

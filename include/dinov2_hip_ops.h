@@ -45,13 +45,15 @@ float dinov2_hip_op_attention_bench(int32_t dtype, int32_t B, int32_t T, int32_t
  * 1 dino_classify_preprocess; sizes from dinov2_hip_preprocess_size).  Replaces dinov2.cpp:106-156 on the device. */
 int dinov2_hip_op_preprocess_u8(int32_t mode, const uint8_t *bgr, int32_t B, int32_t h, int32_t w, int32_t patch, float *out);
 
-/* Shader cycles and 100 MHz wall-clock ticks that workgroup 0 of the LAST FFN-in GEMM launch (the roofline's dominant kernel) on the
- * current device spent in the kernel: cycles / (ticks * 10 ns) = the clock the power-limited part sustained under that load. */
+/* Clock probe.  Workgroup 0 of every launch of the forward's five heavy kernel kinds adds the shader cycles (s_memtime) and the 100 MHz
+ * wall-clock ticks (s_memrealtime) it spent in the kernel to running sums on the device: cycles / (ticks * 10 ns) over a window = the clock
+ * the power-limited part sustained under that kernel's load.  The sums only grow; take differences.
+ * dinov2_hip_op_clock_probe: the FFN-in GEMM (the roofline's dominant kernel).
+ * dinov2_hip_op_clock_slots: out18[3 s] = cycles, out18[3 s + 1] = ticks, out18[3 s + 2] = launches, s = 0 QKV GEMM, 1 attn-out GEMM, 2 FFN-in
+ * GEMM, 3 FFN-out GEMM, 4 attention (its first workgroup's own lifetime), 5 any other GEMM.  bench.py weights the kinds by their share of the
+ * step (`effective_clock_ghz`, `kernel_clocks_ghz`). */
 int dinov2_hip_op_clock_probe(uint64_t *cycles, uint64_t *ticks_100mhz);
-/* The same for the LAST launch of every heavy kernel kind of the forward: out12[2 s] = shader cycles, out12[2 s + 1] = 100 MHz ticks of
- * workgroup 0, s = 0 QKV GEMM, 1 attn-out GEMM, 2 FFN-in GEMM, 3 FFN-out GEMM, 4 attention (its first workgroup's own lifetime), 5 any
- * other GEMM.  bench.py weights them by each kind's share of the step (`effective_clock_ghz`, `kernel_clocks_ghz`). */
-int dinov2_hip_op_clock_slots(uint64_t *out12);
+int dinov2_hip_op_clock_slots(uint64_t *out18);
 
 /* Testing aids.  The switches the library used to read from the environment on every launch (DINOV2_HIP_GEMM_GEN, DINOV2_HIP_GEMM_TILE,
  * DINOV2_HIP_ATTN_V, DINOV2_HIP_ATTN_NWV; include/dinov2_hip.h, "Environment") are read ONCE, on first use; a test that wants to flip one
