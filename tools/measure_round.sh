@@ -27,9 +27,9 @@ timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench.err; cat $O/bench_n1.json
 DINOV2_BENCH_FORCE_DIST=1 timeout 900 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-latency > $O/bench_dist1_forced.json 2> $O/bench_dist1.err; python -c "
 import json; d=json.load(open('$O/bench_dist1_forced.json')); print('forced-dist', d['value'], d['weight_broadcast_ms'], d['broadcast_verified'], d['config4'])"
-rm -rf gpurun_out/prof_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency > $O/bench_under_rocprof.json 2> $O/prof.err; head -14 gpurun_out/prof_$TAG/p_kernel_stats.csv | cut -c1-160; cp gpurun_out/prof_$TAG/p_kernel_stats.csv $O/bench_kernel_stats.csv
-rm -rf gpurun_out/prof_b1_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency --batch 1 --steps 50 --warmup 20 > $O/bench_b1_under_rocprof.json 2> $O/prof_b1.err; cp gpurun_out/prof_b1_$TAG/p_kernel_stats.csv $O/bench_b1_kernel_stats.csv
-rm -rf gpurun_out/prof_b1s_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1s_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency --batch 1 --size 224 --steps 50 --warmup 20 > $O/bench_b1_224_under_rocprof.json 2> $O/prof_b1s.err; cp gpurun_out/prof_b1s_$TAG/p_kernel_stats.csv $O/bench_b1_224_kernel_stats.csv
+rm -rf gpurun_out/prof_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency > $O/bench_under_rocprof.json 2> $O/prof.err; head -14 gpurun_out/prof_$TAG/p_kernel_stats.csv | cut -c1-160; cp gpurun_out/prof_$TAG/p_kernel_stats.csv $O/bench_kernel_stats.csv; rm -rf gpurun_out/prof_$TAG
+rm -rf gpurun_out/prof_b1_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency --batch 1 --steps 50 --warmup 20 > $O/bench_b1_under_rocprof.json 2> $O/prof_b1.err; cp gpurun_out/prof_b1_$TAG/p_kernel_stats.csv $O/bench_b1_kernel_stats.csv; rm -rf gpurun_out/prof_b1_$TAG
+rm -rf gpurun_out/prof_b1s_$TAG; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_b1s_$TAG -o p -- python bench.py --no-cpu-baseline --no-latency --batch 1 --size 224 --steps 50 --warmup 20 > $O/bench_b1_224_under_rocprof.json 2> $O/prof_b1s.err; cp gpurun_out/prof_b1s_$TAG/p_kernel_stats.csv $O/bench_b1_224_kernel_stats.csv; rm -rf gpurun_out/prof_b1s_$TAG
 timeout 900 bash tools/hbm_traffic.sh; cp gpurun_out/hbm_traffic.json $O/
 timeout 600 bash tools/mfma_util.sh; cp gpurun_out/mfma_util.json $O/
 timeout 1800 bash tools/other_configs.sh; cp gpurun_out/bench_base_b1.json gpurun_out/bench_giant_bf16_b8.json gpurun_out/bench_large_q8_0.json gpurun_out/bench_large_q4_0.json $O/
@@ -47,4 +47,7 @@ timeout 600 python bench.py --front group --gpus 1 --steps 10 --warmup 2 --windo
 timeout 600 python bench.py --front group --gpus 4 --devices 0,0,0,0 --batch 8 --steps 5 --warmup 2 --windows 2 > $O/bench_front_group_dup4.json 2>> $O/bench_front_group.err
 stamp_csv $O/*.csv
 stamp_json $O/*.json
+# gpurun copies back at most 64 MiB: the raw rocprofv3 traces / counter dumps have been reduced to the files in $O above
+rm -rf gpurun_out/prof_* gpurun_out/hbm_FETCH_SIZE gpurun_out/hbm_WRITE_SIZE gpurun_out/pmc_* gpurun_out/trace_*
+du -sh gpurun_out $O
 ls $O
