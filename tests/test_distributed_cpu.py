@@ -68,3 +68,18 @@ def test_shard_range_properties(pkg):
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
     assert D.shard_range(64, 8, 3) == (24, 32)  # BASELINE config 4: 64 images = 8 x 8
+
+
+def test_bench_watchdog_exits_with_stage_and_rank():
+    """bench.py's watchdog: a collective set-up stage that overruns its budget ends the process with exit code 4 and a
+    message that names the stage and the rank -- instead of a hang that only the driver's timeout would end."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "wd = bench.Watchdog(3)\n"
+            "with wd.stage('quick stage', 5.0):\n    pass\n"
+            "with wd.stage('weight-arena broadcast (test)', 0.6):\n    time.sleep(30)\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 4, (r.returncode, r.stderr[-500:])
+    assert "rank 3" in r.stderr and "weight-arena broadcast (test)" in r.stderr and "quick stage" not in r.stderr
