@@ -139,6 +139,13 @@ static __device__ __forceinline__ void gemm2_body(const GemmArgs& p, char* smem)
         const bool half8 = h == 1 && RX1 == 32;
         if (h == 1 && ONE) return;
         char* dst = smem + buf * BUF + (ONE && h >= 2 ? h - 1 : h) * 16384 + (half8 ? wid : 2 * wid) * 1024;
+#ifdef DINO_GEMM2_NTX  // tuning builds: non-temporal LDS-DMA for the X pieces of the residual epilogue (profiles/r05_gemm4_nt_loads.txt)
+        if (EPI == EPI_RESID && h < 2) {
+            __builtin_amdgcn_global_load_lds((const DINO_GLOBAL_AS void*)(base + src[h][0]), (DINO_LDS_AS void*)dst, 16, 0, 2);
+            if (!half8) __builtin_amdgcn_global_load_lds((const DINO_GLOBAL_AS void*)(base + src[h][1]), (DINO_LDS_AS void*)(dst + 1024), 16, 0, 2);
+            return;
+        }
+#endif
         glds16(base + src[h][0], dst);
         if (!half8) glds16(base + src[h][1], dst + 1024);
     };

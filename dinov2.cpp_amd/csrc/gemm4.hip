@@ -63,6 +63,13 @@ static __device__ __forceinline__ void static_for(F&& f) {
 #define DINO4_GLDS(VOFF, SBASE, LDSBASE, IMM)                                                                                   \
     asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(VOFF), "s"(SBASE), "s"(LDSBASE), "n"(IMM) \
                  : "memory", "scc")
+// (tuning builds, -DDINO_GEMM4_NT=1|2|3|4: non-temporal LDS-DMA for the X pieces / the W pieces / both / the X pieces of the residual epilogue only -- profiles/r05_gemm4_nt_loads.txt)
+#define DINO4_GLDS_NT(VOFF, SBASE, LDSBASE, IMM)                                                                                \
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt" ::"v"(VOFF), "s"(SBASE), "s"(LDSBASE), "n"(IMM) \
+                 : "memory", "scc")
+#ifndef DINO_GEMM4_NT
+#define DINO_GEMM4_NT 0
+#endif
 
 // Clock probe slots of this file's kernels (device_types.h, "clock probe")
 __device__ unsigned long long g_clk4[CLK_SLOTS * 4];
@@ -190,8 +197,14 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
         constexpr int pc__ = (PC);                                                                                          \
         constexpr bool isw__ = pc__ >= 2 * NI || (pc__ & 1);                                                                \
         constexpr int rb__ = pc__ >= 2 * NI ? pc__ - NI : pc__ >> 1;                                                        \
-        if constexpr (isw__) DINO4_GLDS(so[pc__], Wb + (size_t)(KT) * 128, ldsw, (BUF) * 32768 + rb__ * 1024);              \
-        else DINO4_GLDS(so[pc__], Ab + (size_t)(KT) * 128, ldsx, (BUF) * 32768 + rb__ * 1024);                               \
+        if constexpr (isw__) {                                                                                              \
+            if constexpr (DINO_GEMM4_NT & 2) DINO4_GLDS_NT(so[pc__], Wb + (size_t)(KT) * 128, ldsw, (BUF) * 32768 + rb__ * 1024);   \
+            else DINO4_GLDS(so[pc__], Wb + (size_t)(KT) * 128, ldsw, (BUF) * 32768 + rb__ * 1024);                          \
+        } else {                                                                                                            \
+            if constexpr ((DINO_GEMM4_NT & 1) || ((DINO_GEMM4_NT & 4) && EPI == EPI_RESID))                                 \
+                DINO4_GLDS_NT(so[pc__], Ab + (size_t)(KT) * 128, ldsx, (BUF) * 32768 + rb__ * 1024);                        \
+            else DINO4_GLDS(so[pc__], Ab + (size_t)(KT) * 128, ldsx, (BUF) * 32768 + rb__ * 1024);                          \
+        }                                                                                                                   \
     }
 
     // One K-tile in buffer B.  FIRST: the accumulators start from zero (first K-tile of an output tile).  Staging under it: the slots up
