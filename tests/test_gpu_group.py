@@ -295,3 +295,63 @@ def test_fetch_refused_after_the_workspace_was_overwritten(api, golden_dir):
     bad = api.Input(0, 2, 56, 84, api.RGB_CHW, 0)  # null data: fails in the argument checks, before anything ran
     assert L.dinov2_hip_predict(sess._h, C.byref(bad), None, api.CLASSIFY, err, len(err)) == 4
     assert L.dinov2_hip_fetch(sess._h, C.byref(o), err, len(err)) == 0  # the workspace was not touched: the last forward is still there
+
+
+def test_group_predict_races_a_submitting_thread(api, golden_dir):
+    """dinov2_hip_group_predict used to check "no un-waited ticket" in one critical section and enqueue in another, so a
+    submit from a second thread could slip in between and orphan predict's ticket (a job nobody could wait for, writing into the caller's
+    buffers).  Two threads hammer one group -- A calls the blocking predict, B keeps one ticket in flight with submit / wait -- for a few
+    hundred rounds: every call either succeeds with the single-session bits or is REFUSED with the documented error; nothing hangs, and
+    when both are done the pipeline is empty (a plain predict succeeds)."""
+    import threading
+    gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    grp = api.Group(gguf, devices=[0, 0], classify=True, streams_per_device=2)
+    sess = api.Session(api.Model(gguf, classify=True))
+    rng = np.random.default_rng(21)
+    a_img, b_img = (rng.standard_normal((3, 3, 56, 84)).astype(np.float32) for _ in range(2))
+    ref_a, ref_b = sess.predict(a_img, classify=True)["logits"], sess.predict(b_img, classify=True)["logits"]
+    stats = {"a_ok": 0, "a_refused": 0, "b_ok": 0, "b_refused": 0, "bad": []}
+    stop = threading.Event()
+
+    def thread_a():
+        for _ in range(300):
+            try:
+                out = grp.predict(a_img, classify=True, want=("logits",))
+                if not np.array_equal(out["logits"], ref_a):
+                    stats["bad"].append("A: wrong bits")
+                stats["a_ok"] += 1
+            except api.DinoError as e:
+                if "not waited for yet" not in str(e) and "in flight" not in str(e) and "submission order" not in str(e):
+                    stats["bad"].append("A: " + str(e))
+                stats["a_refused"] += 1
+        stop.set()
+
+    def thread_b():
+        while not stop.is_set():
+            try:
+                h = grp.submit(b_img, classify=True, want=("logits",))
+            except api.DinoError as e:
+                if "in flight" not in str(e):
+                    stats["bad"].append("B submit: " + str(e))
+                stats["b_refused"] += 1
+                continue
+            while True:  # a ticket taken by B must be waitable by B: predict's own ticket may be ahead of it for a moment
+                try:
+                    out = grp.wait(h)
+                    break
+                except api.DinoError as e:
+                    if "submission order" not in str(e):
+                        stats["bad"].append("B wait: " + str(e))
+                        return
+            if not np.array_equal(out["logits"], ref_b):
+                stats["bad"].append("B: wrong bits")
+            stats["b_ok"] += 1
+
+    ta, tb = threading.Thread(target=thread_a), threading.Thread(target=thread_b)
+    ta.start(); tb.start()
+    ta.join(timeout=300); stop.set(); tb.join(timeout=60)
+    assert not ta.is_alive() and not tb.is_alive(), "a call hung"
+    assert not stats["bad"], stats["bad"][:5]
+    assert stats["a_ok"] + stats["a_refused"] == 300 and stats["b_ok"] > 0
+    assert np.array_equal(grp.predict(a_img, classify=True, want=("logits",))["logits"], ref_a)  # the pipeline is empty and usable
+    grp.close()
