@@ -24,6 +24,27 @@ CONFIGS = {
 }
 
 
+# ---- "trained-like" statistics (write_synthetic_gguf(trained_like=True)) ----
+TRAINED_HEAD_SCALES = (1.0, 1.5, 2.0, 2.5, 3.0, 3.5)  # q and k rows of head hd in layer i scaled by [(hd + i) % 6]: scores x 1 .. x 12
+TRAINED_OUTLIER_BIAS = (90.0, -70.0, 110.0, -80.0)    # fc2.bias of the outlier channels in the layer that creates them (layer_scale2 = 1 there)
+TRAINED_OUTLIER_ROW_GAIN = 20.0                        # that layer's fc2 rows of the outlier channels: the token-dependent part
+TRAINED_SINK_VALUE = 6.0                               # register-token embedding on the sink channels (other entries ~ N(0, 0.5))
+TRAINED_SINK_KEY = 0.35                                # key weight from a sink channel onto the head's sink direction
+TRAINED_SINK_QUERY = 6.0                               # query bias along that direction
+
+
+def trained_outlier_channels(H: int) -> list:
+    return [7, H // 3 + 5, H - 11] + ([H // 2 + 3] if H >= 1024 else [])
+
+
+def trained_sink_channels(H: int) -> list:
+    return [H // 8 + 2 * j + 1 for j in range(8)]
+
+
+def trained_outlier_layer(L: int) -> int:
+    return max(0, min(L - 2, L // 6))
+
+
 def flops_per_image(cfg: dict, height: int, width: int, registers: int, num_classes: int) -> float:
     """Algorithmic FLOPs of one forward; padding FLOPs do not count."""
     H, L, F, p = cfg["hidden"], cfg["layers"], cfg["ffn"], cfg["patch"]
@@ -35,7 +56,8 @@ def flops_per_image(cfg: dict, height: int, width: int, registers: int, num_clas
 
 
 def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: int = 4, num_classes: int = 1000,
-                         seed: int = 42, wtype: str = "f16", layers: int | None = None, head_std: float = 0.02) -> dict:
+                         seed: int = 42, wtype: str = "f16", layers: int | None = None, head_std: float = 0.02,
+                         trained_like: bool = False) -> dict:
     """Write a seeded random DINOv2 GGUF.  Returns the hparams dict.
 
     wtype: storage type of the 2-D `*.weight` matrices ("f16", "f32", "q4_0", "q4_1", "q5_0", "q5_1",
@@ -43,6 +65,17 @@ def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: i
     their dtypes, dinov2.cpp:227-236).
     head_std: standard deviation of the classifier weights.  0.02 gives max|logit| ~ 2-3 over 1000 classes; trained
     ImageNet heads produce |logit| of 10-20, which 0.12 reproduces (used by the absolute-error parity test).
+    trained_like: the statistics of a TRAINED DINOv2 that i.i.d. N(0, 0.02) weights lack and that
+    decide whether f16 attention operands / f16 activations are good enough:
+      * peaky attention: the q and k rows of every head are scaled by a per-head factor from TRAINED_HEAD_SCALES, so that the
+        pre-softmax |score| of several heads reaches 30 - 60 (ggml keeps q, k and the scores in f32, dinov2.cpp:527-536);
+      * residual outlier channels: from layer TRAINED_OUTLIER_LAYER(L) on, the channels of trained_outlier_channels(H) sit at
+        ~ 100 x the median |x| (a constant part through `fc2.bias` and a token-dependent part through that layer's fc2 rows),
+        and the LayerNorm weights of those channels are small, as in the released checkpoints;
+      * attention sinks: the register tokens carry a large component on TRAINED_SINK_CHANNELS channels that every second head's
+        keys read out along the direction its query bias points in: all queries of those heads put most of their softmax mass
+        on the registers.
+    Use with head_std = 0.12 for trained-scale logits.  tests/test_gpu_trained_like.py asserts that the regime is reached.
     """
     cfg = dict(CONFIGS[model]) if isinstance(model, str) else dict(model)
     if layers is not None:
@@ -78,40 +111,76 @@ def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: i
     def vec(name, shape, std, mean=0.0):
         w.add_tensor(name, (normal(shape, std) + np.float32(mean)).astype(np.float32))
 
+    out_ch = trained_outlier_channels(H) if trained_like else []
+    sink_ch = trained_sink_channels(H) if trained_like else []
+    l_out = trained_outlier_layer(L)
+
+    # once the outlier channels exist they dominate every row's variance: trained LayerNorm weights make up for it (large on the ordinary
+    # channels, small on the outliers), so that the layers behind keep seeing O(1) inputs
+    restore = np.float32(np.sqrt(1.0 + sum(b * b for b in TRAINED_OUTLIER_BIAS[: len(out_ch)]) / H))
+
+    def norm_weight(name, after_outliers=False):
+        g = normal((H,), 0.1) + np.float32(1.0)
+        if trained_like:
+            if after_outliers:
+                g *= restore
+            g[out_ch] = np.float32(0.04) * np.sign(g[out_ch])
+        w.add_tensor(name, g.astype(np.float32))
+
     vec("embeddings.cls_token", (1, 1, H), 0.5)
     vec("embeddings.position_embeddings", (1, 1 + M * M, H), 0.3)
     if registers > 0:
-        vec("embeddings.register_tokens", (1, registers, H), 0.5)
+        reg = normal((1, registers, H), 0.5)
+        if trained_like:
+            reg[0, :, sink_ch] = np.float32(TRAINED_SINK_VALUE)
+        w.add_tensor("embeddings.register_tokens", reg)
     w.add_tensor("embeddings.patch_embeddings.projection.weight", normal((H, 3, p, p), 0.04).astype(np.float16))
     vec("embeddings.patch_embeddings.projection.bias", (1, H, 1, 1), 0.1)
     for i in range(L):
         b = f"encoder.layer.{i}."
-        vec(b + "norm1.weight", (H,), 0.1, 1.0)
+        norm_weight(b + "norm1.weight", i > l_out)
         vec(b + "norm1.bias", (H,), 0.05)
         qkv = normal((3 * H, H), 0.02)
         qkv[: 2 * H] *= np.float32(2.0)  # peakier attention than the near-uniform default
+        qkv_bias = normal((3 * H,), 0.05)
+        if trained_like:
+            for hd in range(nh):
+                # (x sqrt(384 / H) x 0.75: the score of a random q . k grows with H; this keeps every model of the family in the same regime)
+                sc = np.float32(TRAINED_HEAD_SCALES[(hd + i) % len(TRAINED_HEAD_SCALES)] * 0.75 * np.sqrt(384.0 / H))
+                qkv[hd * 64:(hd + 1) * 64] *= sc
+                qkv[H + hd * 64:H + (hd + 1) * 64] *= sc
+                if hd % 2 == 0 and registers > 0:  # a sink head: keys read the registers' sink channels out along d, the query bias points along d
+                    d = rng.standard_normal(64).astype(np.float32)
+                    d /= np.linalg.norm(d)
+                    qkv[H + hd * 64:H + (hd + 1) * 64][:, sink_ch] += np.float32(TRAINED_SINK_KEY) * d[:, None]
+                    qkv_bias[hd * 64:(hd + 1) * 64] += np.float32(TRAINED_SINK_QUERY) * d
         if gt in (gw.GGML_F32, gw.GGML_F16):
             w.add_tensor(b + "attention.attention.qkv.weight", qkv.astype(np.float16) if gt == gw.GGML_F16 else qkv)
         else:
             w.add_tensor(b + "attention.attention.qkv.weight", qkv, gtype=gt)
-        vec(b + "attention.attention.qkv.bias", (3 * H,), 0.05)
+        w.add_tensor(b + "attention.attention.qkv.bias", qkv_bias)
         mat(b + "attention.output.dense.weight", (H, H), 0.02)
         vec(b + "attention.output.dense.bias", (H,), 0.05)
         vec(b + "layer_scale1.lambda1", (H,), 0.1, 0.3)
-        vec(b + "norm2.weight", (H,), 0.1, 1.0)
+        norm_weight(b + "norm2.weight", i > l_out)
         vec(b + "norm2.bias", (H,), 0.05)
-        if cfg["swiglu"]:
-            mat(b + "mlp.weights_in.weight", (2 * F, H), 0.02)
-            vec(b + "mlp.weights_in.bias", (2 * F,), 0.05)
-            mat(b + "mlp.weights_out.weight", (H, F), 0.02)
-            vec(b + "mlp.weights_out.bias", (H,), 0.05)
+        fc1n, fc2n = ("mlp.weights_in", "mlp.weights_out") if cfg["swiglu"] else ("mlp.fc1", "mlp.fc2")
+        mat(b + fc1n + ".weight", (2 * F if cfg["swiglu"] else F, H), 0.02)
+        vec(b + fc1n + ".bias", (2 * F if cfg["swiglu"] else F,), 0.05)
+        fc2 = normal((H, F), 0.02)
+        fc2_bias = normal((H,), 0.05)
+        ls2 = normal((H,), 0.1) + np.float32(0.3)
+        if trained_like and i == l_out:  # the layer that writes the outlier channels into the residual stream
+            fc2[out_ch] *= np.float32(TRAINED_OUTLIER_ROW_GAIN)
+            fc2_bias[out_ch] = np.asarray(TRAINED_OUTLIER_BIAS[: len(out_ch)], np.float32)
+            ls2[out_ch] = np.float32(1.0)
+        if gt in (gw.GGML_F32, gw.GGML_F16):
+            w.add_tensor(b + fc2n + ".weight", fc2.astype(np.float16) if gt == gw.GGML_F16 else fc2)
         else:
-            mat(b + "mlp.fc1.weight", (F, H), 0.02)
-            vec(b + "mlp.fc1.bias", (F,), 0.05)
-            mat(b + "mlp.fc2.weight", (H, F), 0.02)
-            vec(b + "mlp.fc2.bias", (H,), 0.05)
-        vec(b + "layer_scale2.lambda1", (H,), 0.1, 0.3)
-    vec("layernorm.weight", (H,), 0.1, 1.0)
+            w.add_tensor(b + fc2n + ".weight", fc2, gtype=gt)
+        w.add_tensor(b + fc2n + ".bias", fc2_bias)
+        w.add_tensor(b + "layer_scale2.lambda1", ls2)
+    norm_weight("layernorm.weight", True)
     vec("layernorm.bias", (H,), 0.05)
     if num_classes > 0:
         mat("classifier.weight", (num_classes, 2 * H), head_std)
