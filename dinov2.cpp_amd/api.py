@@ -41,7 +41,7 @@ class DinoError(RuntimeError):
 class LoadOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("compute_dtype", C.c_int32), ("classify", C.c_int32),
                 ("skip_tensor_data", C.c_int32), ("quirk_pool_const_divisor", C.c_int32),
-                ("quirk_pool_includes_registers", C.c_int32), ("batch_invariant", C.c_int32), ("reserved", C.c_int32 * 9)]
+                ("quirk_pool_includes_registers", C.c_int32), ("batch_invariant", C.c_int32), ("ln_fold", C.c_int32), ("reserved", C.c_int32 * 8)]
 
 
 class HParams(C.Structure):
@@ -152,6 +152,10 @@ def lib():
     fp = C.POINTER(C.c_float)
     L.dinov2_hip_op_gemm.argtypes = [i32, i32, fp, fp, fp, fp, C.c_int64, fp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                      C.c_float]
+    L.dinov2_hip_op_gemm_resid_ln.argtypes = [i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32]
+    L.dinov2_hip_op_gemm_ln_consumer.argtypes = [i32, i32, fp, fp, fp, fp, fp, C.c_float, fp, i32, i32, i32, i32, i32, C.c_float]
+    L.dinov2_hip_op_ln_prepare.argtypes = [i32, fp, fp, fp, fp, i32, i32]
+    L.dinov2_hip_op_ln_fold_vectors.argtypes = [i32, fp, fp, fp, fp, fp, fp, i32, i32]
     L.dinov2_hip_op_attention.argtypes = [i32, fp, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_layernorm.argtypes = [i32, fp, fp, fp, fp, i32, i32, C.c_float]
     L.dinov2_hip_op_convert_weight.argtypes = [i32, vp, C.c_uint64, u32, fp, i32, i32, i32, i32]
@@ -210,7 +214,8 @@ class Model:
 
     def __init__(self, path: str, *, device: int = 0, dtype: int = F16, classify: bool = True,
                  skip_tensor_data: bool = False, pool_const_divisor: bool = True, pool_includes_registers: bool = True,
-                 batch_invariant: bool = True):
+                 batch_invariant: bool = True, ln_fold: int = 0):
+        """ln_fold: 0 = the library's choice, 1 = LayerNorm folded into the neighbouring GEMMs, -1 = separate LayerNorm launches."""
         L = lib()
         o = LoadOpts()
         L.dinov2_hip_default_load_opts(C.byref(o))
@@ -218,6 +223,7 @@ class Model:
         o.skip_tensor_data = int(skip_tensor_data)
         o.quirk_pool_const_divisor, o.quirk_pool_includes_registers = int(pool_const_divisor), int(pool_includes_registers)
         o.batch_invariant = int(batch_invariant)
+        o.ln_fold = int(ln_fold)
         h = C.c_void_p()
         err = _errbuf()
         rc = L.dinov2_hip_model_load(path.encode(), C.byref(o), C.byref(h), err, len(err))

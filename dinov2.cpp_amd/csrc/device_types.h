@@ -61,17 +61,21 @@ enum ClockSlot : int { CLK_QKV = 0, CLK_ATTN_OUT = 1, CLK_FFN_IN = 2, CLK_FFN_OU
         ck_c0__ = __builtin_readcyclecounter();                      \
         ck_r0__ = __builtin_amdgcn_s_memrealtime();                  \
     }
-#define DINO_CLK_END(ARR, SLOT)                                               \
-    if (ck_on__) {                                                            \
-        const unsigned long long ck_r1__ = __builtin_amdgcn_s_memrealtime();  \
-        (ARR)[(SLOT) * 4 + 0] += __builtin_readcyclecounter() - ck_c0__;      \
-        (ARR)[(SLOT) * 4 + 1] += ck_r1__ - ck_r0__;                           \
-        (ARR)[(SLOT) * 4 + 2] = ck_r1__;                                      \
-        (ARR)[(SLOT) * 4 + 3] += 1;                                           \
+// (atomic adds: two sessions on concurrent streams of one device -- the group front's lanes -- may end launches of one kind at the same time)
+#define DINO_CLK_END(ARR, SLOT)                                                                  \
+    if (ck_on__) {                                                                               \
+        const unsigned long long ck_r1__ = __builtin_amdgcn_s_memrealtime();                     \
+        atomicAdd(&(ARR)[(SLOT) * 4 + 0], (unsigned long long)(__builtin_readcyclecounter() - ck_c0__)); \
+        atomicAdd(&(ARR)[(SLOT) * 4 + 1], ck_r1__ - ck_r0__);                                    \
+        (ARR)[(SLOT) * 4 + 2] = ck_r1__;                                                         \
+        atomicAdd(&(ARR)[(SLOT) * 4 + 3], 1ull);                                                 \
     }
-// which slot a GEMM launch belongs to (EPI: kernels.h Epilogue; the residual epilogue serves attn-out, K = N, and FFN-out, K > N)
-#define DINO_CLK_GEMM_SLOT(EPI, N, K) \
-    ((EPI) == 1 ? CLK_QKV : (EPI) == 2 ? ((K) > (N) ? CLK_FFN_OUT : CLK_ATTN_OUT) : ((EPI) == 3 || (EPI) == 4) ? CLK_FFN_IN : CLK_OTHER)
+// which slot a GEMM launch belongs to (EPI: kernels.h Epilogue incl. the LN-fold variants; the residual epilogue serves attn-out, K = N, and
+// FFN-out, K > N).  Evaluated ONCE per logical launch by launch_gemm on the caller's N and K (GemmArgs::clk_slot): the parts of a split
+// launch see a smaller N (ViT-S attn-out, N = 384 -> 256 + 128, was counted as FFN-out).
+#define DINO_CLK_GEMM_SLOT(EPI, N, K)                                                                                             \
+    (((EPI) == 1 || (EPI) == 7) ? CLK_QKV : ((EPI) == 2 || (EPI) == 6) ? ((K) > (N) ? CLK_FFN_OUT : CLK_ATTN_OUT)                   \
+                                          : ((EPI) == 3 || (EPI) == 4 || (EPI) == 8 || (EPI) == 9) ? CLK_FFN_IN : CLK_OTHER)
 
 // 16-byte async global -> LDS copy (global_load_lds_dwordx4): LDS destination = wave-uniform `lds` + lane*16
 static __device__ __forceinline__ void glds16(const void* gsrc, void* lds) {
@@ -84,6 +88,73 @@ static __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int xcd = bid & 7, idx = bid >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---- LN fold (kernels.h, EPI_RESID_LN and the *_LN consumers) -------------------------------------------------------------------------
+// DPP lane exchange inside rows of 16 lanes: quad_perm [1,0,3,2] / [2,3,0,1] (xor 1 / xor 2), row_half_mirror (7 - i within 8 lanes: the other
+// quad once both quads are uniform), row_mirror (15 - i: the other half once both halves are uniform)
+template <int CTRL>
+static __device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// (sum, sum of squares) of four consecutive columns: the leaves of the fixed pairwise tree every producer uses
+static __device__ __forceinline__ void ln_leaf4(float a, float b, float c, float d, float& s, float& q) {
+#pragma clang fp contract(off)
+    s = (a + b) + (c + d);
+    q = (a * a + b * b) + (c * c + d * d);
+}
+// LayerNorm coefficients of one row from its per-64-column partial sums: y = r * (acc - mean * s[n]) + c[n] = fma(r, acc, fma(nrm, s[n], c[n]))
+// with r = 1 / sqrt(var + eps), nrm = -mean * r.  A row of the statistics buffer holds 12 or 24 group slots (ln_gs: 12 for hidden <= 768;
+// slots past hidden / 64 are zero and stay zero), so a reader needs no bounds: it takes whole halves of twelve slots with immediate
+// offsets from one address -- anything computed per group would be hoisted out of the persistent tile loops as dozens of loop invariants.
+// In steps, so that a caller can put work between the requests and their use and never holds more than twelve slots in registers:
+// load half 0 / add it / (24-slot rows: load half 1 / add it) / finish.  Slots are added in ascending order in f32.
+struct LnRaw {  // one HALF of a row's slots: [0, 12) or [12, 24)
+    float2 g[12];
+};
+struct LnAcc {
+    float S, Q;
+};
+template <int HALF>
+static __device__ __forceinline__ void ln_row_load(const float* __restrict__ stats, int row, int gs, LnRaw& raw) {
+    const float2* p = (const float2*)(stats + (size_t)row * gs * 2) + 12 * HALF;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) raw.g[g] = p[g];
+}
+// (f32, slot after slot in ascending order: the slots are f32 sums of 64 elements each, at most 24 of them; double costs a one-wave-per-SIMD
+//  epilogue ~ 1.5 us per tile in dependent half-rate adds and buys nothing next to the 2^-11 rounding of the operand)
+template <int HALF>
+static __device__ __forceinline__ void ln_row_add(const LnRaw& raw, LnAcc& a) {
+#pragma clang fp contract(off)
+    if (HALF == 0) a.S = a.Q = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 12; ++g) {
+        a.S += raw.g[g].x;
+        a.Q += raw.g[g].y;
+    }
+}
+static __device__ __forceinline__ void ln_row_finish(const LnAcc& a, float inv_h, float eps, float& r, float& nrm) {
+#pragma clang fp contract(off)
+    const float mean = a.S * inv_h;
+    float var = a.Q * inv_h - mean * mean;
+    var = var > 0.0f ? var : 0.0f;
+    const float rs = 1.0f / sqrtf(var + eps);
+    r = rs;
+    nrm = -mean * rs;
+}
+
+// The same from partial sums that already sit in LDS (the small-tile kernel stages its tile's rows there by LDS-DMA): a plain loop, no
+// register staging.  Same summation order, same bits.
+static __device__ __forceinline__ void ln_row_coeffs_lds(const float2* p, int gs, float inv_h, float eps, float& r, float& nrm) {
+#pragma clang fp contract(off)
+    LnAcc a;
+    a.S = a.Q = 0.0f;
+    for (int g = 0; g < gs; ++g) {  // (all gs slots, the zero ones included: the order and the bits of ln_row_add)
+        const float2 v = p[g];
+        a.S += v.x;
+        a.Q += v.y;
+    }
+    ln_row_finish(a, inv_h, eps, r, nrm);
 }
 
 // ggml tanh-GELU (ggml_gelu_f32)

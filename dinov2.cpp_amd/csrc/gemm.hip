@@ -68,7 +68,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int WTM = BM / WM, WTN = BN / WN;  // wave tile
     constexpr int MREP = WTM / 16, NREP = WTN / 16;  // 16 x 16 accumulator blocks of the wave tile (MFMA 16x16x32)
     constexpr int AI = BM / 8 / NW, BI = BN / 8 / NW;  // glds wave-instructions per wave per tile
-    static_assert(NREP == 4 || EPI != EPI_SWIGLU, "the SwiGLU pairing assumes a 64-wide wave tile");
+    static_assert(NREP == 4 || (EPI != EPI_SWIGLU && EPI != EPI_SWIGLU_LN), "the SwiGLU pairing assumes a 64-wide wave tile");
+    // LN fold (kernels.h): LNC = this GEMM consumes T(gamma x) and applies the LayerNorm in its epilogue; EB = the epilogue it specialises
+    constexpr bool LNC = EPI == EPI_QKV_LN || EPI == EPI_GELU_LN || EPI == EPI_SWIGLU_LN;
+    constexpr int EB = EPI == EPI_RESID_LN ? EPI_RESID : EPI == EPI_QKV_LN ? EPI_QKV : EPI == EPI_GELU_LN ? EPI_GELU : EPI == EPI_SWIGLU_LN ? EPI_SWIGLU : EPI;
 
     extern __shared__ __attribute__((aligned(16))) char smem_all[];
     DINO_SP_INIT
@@ -138,15 +141,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // acc[i][j][r] is C[row, col]: row = m0 + wm*WTM + i*16 + (lane&15), col = n0 + wn*WTN + j*16 + 4*(lane>>4) + r.
     const int colb = n0 + wn * WTN + 4 * fh;
     const int rowb = m0 + wm * WTM + fr;
-    const bool vec_ok = EPI != EPI_SWIGLU && EPI != EPI_PATCH && n0 + BN <= N && (p.ldo & 3) == 0 && (p.qcols & 3) == 0 &&
-                        (((size_t)p.bias | (size_t)p.aux) & 15) == 0;
-    f32x4 bias4[NREP], aux4[NREP], xin4[EPI == EPI_RESID ? MREP : 1][NREP];
+    const bool vec_ok = EB != EPI_SWIGLU && EPI != EPI_PATCH && n0 + BN <= N && (p.ldo & 3) == 0 && (p.qcols & 3) == 0 &&
+                        (((size_t)p.bias | (size_t)p.aux | (size_t)p.ln_s | (size_t)p.ln_c | (size_t)p.ln_gamma) & 15) == 0;
+    // bias4: the additive per-column term (LN consumers: c[n], which contains the bias); lns4: LN consumers' s[n]
+    f32x4 bias4[NREP], aux4[NREP], lns4[LNC ? NREP : 1], xin4[EB == EPI_RESID ? MREP : 1][NREP];
     if (vec_ok) {
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
             const int col0 = colb + jn * 16;
-            bias4[jn] = p.bias ? *(const f32x4*)(p.bias + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_RESID) {
+            if constexpr (LNC) {
+                bias4[jn] = *(const f32x4*)(p.ln_c + col0);
+                lns4[jn] = *(const f32x4*)(p.ln_s + col0);
+            } else {
+                bias4[jn] = p.bias ? *(const f32x4*)(p.bias + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if constexpr (EB == EPI_RESID) {
                 aux4[jn] = *(const f32x4*)(p.aux + col0);
 #pragma unroll
                 for (int i = 0; i < MREP; ++i) {
@@ -164,6 +173,18 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int LPT = KSUB * (AI + BI);  // glds instructions per wave per stage
     static_assert((NST - 2) * LPT < 64, "vmcnt is 6 bits");
     const int nk = (K / BK) / KSUB;
+    // LN consumers: the partial sums of this tile's rows ([BM][K / 64] x (sum, sum of squares)) go to LDS behind the ring by LDS-DMA,
+    // AHEAD of the first stages (so every counted wait of the K loop covers them); they are turned into coefficients after the loop.
+    float2* const lnst = (float2*)(smem_all + NST * STAGE);
+    if constexpr (LNC) {
+        const int hg = p.ln_gs / 2;  // 16-byte chunks per row of the statistics buffer
+        const int nch = BM * hg;
+        for (int f = wid * 64 + lane; f < nch; f += NW * 64) {
+            const int r_ = f / hg, c_ = f - r_ * hg;
+            const int gm = m0 + r_ < M ? m0 + r_ : M - 1;
+            glds16(p.stats + ((size_t)gm * hg + c_) * 4, (char*)lnst + (size_t)(f - lane) * 16);
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
@@ -206,10 +227,23 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         DINO_SP(3)
     }
 
+    // LN consumers: the LayerNorm coefficients (r, -mean r) of this lane's MREP rows.  The four 16-lane groups each finalise ONE of the
+    // wave tile's 16-row blocks; the others come by lane exchange.
+    float lnr[LNC ? MREP : 1], lnn[LNC ? MREP : 1];
+    if constexpr (LNC) {
+        float r1, n1;
+        ln_row_coeffs_lds(lnst + (size_t)(wm * WTM + (fh % MREP) * 16 + fr) * p.ln_gs, p.ln_gs, 1.0f / (float)K, p.ln_eps, r1, n1);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            lnr[i] = __shfl(r1, fr + 16 * i);
+            lnn[i] = __shfl(n1, fr + 16 * i);
+        }
+    }
+
     // ---- epilogue: acc[i][j][r] is C[row, col] with
     //      row = m0 + wm*WTM + i*16 + (lane&15),  col = n0 + wn*WTN + j*16 + 4*(lane>>4) + r   (r = 0..3: four consecutive columns)
     // Edge-guarded per element in M and N (N = 1000-style shapes take the scalar path for their last columns).
-    if constexpr (EPI == EPI_SWIGLU) {
+    if constexpr (EB == EPI_SWIGLU) {
         // W rows interleaved in 32-blocks: columns 0..31 of the wave's 64 hold x1[32 units], columns 32..63 x2 of the same units
         T* out = (T*)p.out;
 #pragma unroll
@@ -217,14 +251,27 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int c1 = colb + jh * 16 + r, c2 = c1 + 32;
-                const float b1 = (p.bias && c1 < N) ? p.bias[c1] : 0.f;
-                const float b2 = (p.bias && c2 < N) ? p.bias[c2] : 0.f;
+                const float* const bsrc_ = LNC ? p.ln_c : p.bias;
+                const float b1 = (bsrc_ && c1 < N) ? bsrc_[c1] : 0.f;
+                const float b2 = (bsrc_ && c2 < N) ? bsrc_[c2] : 0.f;
+                float s1 = 0.f, s2 = 0.f;
+                if constexpr (LNC) {
+                    s1 = c1 < N ? p.ln_s[c1] : 0.f;
+                    s2 = c2 < N ? p.ln_s[c2] : 0.f;
+                }
                 const int hu = ((n0 + wn * WTN) >> 6) * 32 + jh * 16 + 4 * fh + r;  // hidden unit index
 #pragma unroll
                 for (int i = 0; i < MREP; ++i) {
                     const int row = rowb + i * 16;
                     if (row < M && c2 < N) {
-                        const float h1 = acc[i][jh][r] + b1, h2 = acc[i][jh + 2][r] + b2;
+                        float h1, h2;
+                        if constexpr (LNC) {
+                            h1 = __builtin_fmaf(lnr[i], acc[i][jh][r], __builtin_fmaf(lnn[i], s1, b1));
+                            h2 = __builtin_fmaf(lnr[i], acc[i][jh + 2][r], __builtin_fmaf(lnn[i], s2, b2));
+                        } else {
+                            h1 = acc[i][jh][r] + b1;
+                            h2 = acc[i][jh + 2][r] + b2;
+                        }
                         float sl = h1 * __builtin_amdgcn_rcpf(1.0f + __expf(-h1)) * h2;  // silu(x1) * x2, dinov2.cpp:605
                         asm("" : "+v"(sl));
                         out[(size_t)row * p.ldo + hu] = E::from_f32(sl);
@@ -241,15 +288,21 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
             asm volatile("" ::"v"(bias4[jn]));
-            if constexpr (EPI == EPI_RESID) {
+            if constexpr (LNC) asm volatile("" ::"v"(lns4[jn]));
+            if constexpr (EB == EPI_RESID) {
                 asm volatile("" ::"v"(aux4[jn]));
 #pragma unroll
                 for (int i = 0; i < MREP; ++i) asm volatile("" ::"v"(xin4[i][jn]));
             }
         }
+        // EPI_RESID_LN: per-row partial sums of the 16-column blocks go through LDS (behind the K loop's ring: other waves may still be
+        // reading it), where the 64-column groups are completed in the fixed pairwise order
+        float2* const red = (float2*)(smem_all + NST * STAGE);  // [BM][BN / 16]
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
             const int col0 = colb + jn * 16;
+            f32x4 gam4 = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (EPI == EPI_RESID_LN) gam4 = *(const f32x4*)(p.ln_gamma + col0);
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
                 const int row = rowb + i * 16;
@@ -257,19 +310,38 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][jn][r] + bias4[jn][r];
+                    if constexpr (LNC) v[r] = __builtin_fmaf(lnr[i], acc[i][jn][r], __builtin_fmaf(lnn[i], lns4[jn][r], bias4[jn][r]));
+                    else v[r] = acc[i][jn][r] + bias4[jn][r];
                     asm("" : "+v"(v[r]));
                 }
-                if constexpr (EPI == EPI_RESID) {
+                if constexpr (EB == EPI_RESID) {
                     float* x = (float*)p.out + (size_t)row * p.ldo + col0;
                     const f32x4 xi = xin4[i][jn], au = aux4[jn];
-                    *(f32x4*)x = f32x4{v[0] * au[0] + xi[0], v[1] * au[1] + xi[1], v[2] * au[2] + xi[2], v[3] * au[3] + xi[3]};
+                    const f32x4 xn = f32x4{v[0] * au[0] + xi[0], v[1] * au[1] + xi[1], v[2] * au[2] + xi[2], v[3] * au[3] + xi[3]};
+                    *(f32x4*)x = xn;
+                    if constexpr (EPI == EPI_RESID_LN) {
+                        typename E::vec4 og;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float g = xn[r] * gam4[r];
+                            asm("" : "+v"(g));  // f32 product first, then the rounding (as everywhere)
+                            og[r] = E::from_f32(g);
+                        }
+                        *(typename E::vec4*)((T*)p.xg + (size_t)row * p.ldo + col0) = og;
+                        float s4, q4;
+                        ln_leaf4(xn[0], xn[1], xn[2], xn[3], s4, q4);
+                        s4 += __shfl_xor(s4, 16);  // 8 columns
+                        q4 += __shfl_xor(q4, 16);
+                        s4 += __shfl_xor(s4, 32);  // 16 columns
+                        q4 += __shfl_xor(q4, 32);
+                        if (fh == 0) red[(wm * WTM + i * 16 + fr) * (BN / 16) + wn * NREP + jn] = make_float2(s4, q4);
+                    }
                 } else if constexpr (EPI == EPI_PLAIN_F32) {
                     float* x = (float*)p.out + (size_t)row * p.ldo + col0;
                     *(f32x4*)x = f32x4{v[0], v[1], v[2], v[3]};
                 } else {
                     typename E::vec4 o;
-                    if constexpr (EPI == EPI_QKV) {
+                    if constexpr (EB == EPI_QKV) {
                         const float qs = col0 < p.qcols ? p.qscale : 1.0f;  // (qcols % 4 == 0: one answer for the lane's four columns)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -323,14 +395,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             const int col0 = colb + jn * 16;
             if (col0 >= N) continue;
             const bool full = col0 + 3 < N && (p.ldo & 3) == 0;  // the lane's four columns exist and rows are 16-byte aligned: vector path
-            float bias[4], auxv[4];
+            float bias[4], auxv[4], lnsv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = col0 + r < N ? col0 + r : N - 1;
-                bias[r] = p.bias ? p.bias[col] : 0.f;
+                bias[r] = LNC ? p.ln_c[col] : p.bias ? p.bias[col] : 0.f;
+                lnsv[r] = LNC ? p.ln_s[col] : 0.f;
                 auxv[r] = 0.f;
-                if constexpr (EPI == EPI_RESID) auxv[r] = p.aux[col];
-                if constexpr (EPI == EPI_QKV) auxv[r] = col < p.qcols ? p.qscale : 1.0f;
+                if constexpr (EB == EPI_RESID) auxv[r] = p.aux[col];
+                if constexpr (EB == EPI_QKV) auxv[r] = col < p.qcols ? p.qscale : 1.0f;
             }
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
@@ -339,7 +412,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    v[r] = acc[i][jn][r] + bias[r];
+                    if constexpr (LNC) v[r] = __builtin_fmaf(lnr[i], acc[i][jn][r], __builtin_fmaf(lnn[i], lnsv[r], bias[r]));
+                    else v[r] = acc[i][jn][r] + bias[r];
                     asm("" : "+v"(v[r]));  // f32 value first, then any f16 rounding (no v_fma_mix fusion: gemm2.hip)
                 }
                 if constexpr (EPI == EPI_PATCH) {
@@ -349,7 +423,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (col0 + r < N) x[col0 + r] = v[r] + pe[col0 + r];
-                } else if constexpr (EPI == EPI_RESID) {
+                } else if constexpr (EB == EPI_RESID) {  // (EPI_RESID_LN never gets here: launch_gemm only accepts shapes whose tiles are all vec_ok)
                     float* x = (float*)p.out + (size_t)row * p.ldo;
                     if (full) {
                         const float4 xin = *(const float4*)(x + col0);
@@ -371,7 +445,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                     typename E::vec4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if constexpr (EPI == EPI_QKV) {
+                        if constexpr (EB == EPI_QKV) {
                             float vq = v[r] * auxv[r];
                             asm("" : "+v"(vq));
                             o[r] = E::from_f32(vq);
@@ -406,6 +480,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             }
         }
     }
+    if constexpr (EPI == EPI_RESID_LN) {
+        // the 64-column groups of this tile's rows: (b0 + b1) + (b2 + b3) over the four 16-column blocks, one (row, group) per thread
+        __syncthreads();
+        const float2* const red = (const float2*)(smem_all + NST * STAGE);
+        constexpr int GPT = BN / 64;
+        if (tid < BM * GPT) {
+            const int row = tid / GPT, g = tid % GPT;
+            if (m0 + row < M) {
+#pragma clang fp contract(off)
+                const float2 b0 = red[row * (BN / 16) + 4 * g], b1 = red[row * (BN / 16) + 4 * g + 1], b2 = red[row * (BN / 16) + 4 * g + 2],
+                             b3 = red[row * (BN / 16) + 4 * g + 3];
+                const float2 o = make_float2((b0.x + b1.x) + (b2.x + b3.x), (b0.y + b1.y) + (b2.y + b3.y));
+                *(float2*)(p.stats + ((size_t)(m0 + row) * p.ln_gs + (n0 >> 6) + g) * 2) = o;
+            }
+        }
+    }
     DINO_SP(4)
     DINO_SP_FLUSH
 }
@@ -414,7 +504,8 @@ template <typename T, int BM, int BN, int WM, int WN, int NST, int KSUB = 1>
 static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int ntn = (a.N + BN - 1) / BN, ntm = (a.M + BM - 1) / BM;
     const dim3 grid(ntn * ntm), block(WM * WN * 64);
-    const size_t lds = NST * KSUB * (size_t)(BM + BN) * 128;
+    const size_t lds = NST * KSUB * (size_t)(BM + BN) * 128 + (epi == EPI_RESID_LN ? (size_t)BM * (BN / 16) * 8 : 0) +
+                       (epi_ln_consumer(epi) ? (size_t)BM * a.ln_gs * 8 : 0);
 #define DINO_LAUNCH(E)                                                                             \
     case E:                                                                                        \
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, E, KSUB>), grid, block, lds, st, a); \
@@ -425,8 +516,15 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         DINO_LAUNCH(EPI_RESID)
         DINO_LAUNCH(EPI_GELU)
         DINO_LAUNCH(EPI_PLAIN_F32)
+        DINO_LAUNCH(EPI_RESID_LN)
+        DINO_LAUNCH(EPI_QKV_LN)
+        DINO_LAUNCH(EPI_GELU_LN)
         case EPI_SWIGLU:  // (its column pairing needs 64-wide wave tiles)
             if constexpr (BN / WN == 64) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, EPI_SWIGLU, KSUB>), grid, block, lds, st, a);
+            else return hipErrorInvalidValue;
+            break;
+        case EPI_SWIGLU_LN:
+            if constexpr (BN / WN == 64) hipLaunchKernelGGL((gemm_kernel<T, BM, BN, WM, WN, NST, EPI_SWIGLU_LN, KSUB>), grid, block, lds, st, a);
             else return hipErrorInvalidValue;
             break;
     }
@@ -465,7 +563,7 @@ static hipError_t launch_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
 
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KSUB = 1>
 static hipError_t set_attr_cfg() {
-    const int lds = NST * KSUB * (BM + BN) * 128;
+    const int lds = NST * KSUB * (BM + BN) * 128 + BM * LN_MAX_GROUPS * 8;  // (+ the LN-fold variants' row statistics, <= 24 KiB)
     hipError_t e = hipSuccess;
 #define DINO_ATTR(E)                                                                                          \
     if (e == hipSuccess)                                                                                      \
@@ -476,7 +574,11 @@ static hipError_t set_attr_cfg() {
     DINO_ATTR(EPI_RESID)
     DINO_ATTR(EPI_GELU)
     DINO_ATTR(EPI_PLAIN_F32)
+    DINO_ATTR(EPI_RESID_LN)
+    DINO_ATTR(EPI_QKV_LN)
+    DINO_ATTR(EPI_GELU_LN)
     if constexpr (BN / WN == 64) DINO_ATTR(EPI_SWIGLU)
+    if constexpr (BN / WN == 64) DINO_ATTR(EPI_SWIGLU_LN)
 #undef DINO_ATTR
     return e;
 }
@@ -497,14 +599,6 @@ hipError_t launch_gemm4(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t s
 hipError_t launch_gemm4_mixed(DType dt, Epilogue epi, const GemmArgs& a, const GemmArgs& b, hipStream_t st);
 hipError_t launch_gemm4_short(DType dt, Epilogue epi, const GemmArgs& a, int ni, hipStream_t st);  // 32 ni-row tiles, one per workgroup
 hipError_t gemm4_init();
-#ifdef DINO_WITH_GEMM5
-// tools/probes/gemm5.hip (opt-in build, `make g5`): 192 x 128 tiles on four waves, TWO independent workgroups per CU (one's epilogue under
-// the other's K loop).  Measured slower than the generations above on every GEMM of the forward (profiles/r05_gemm5.md): not in the product.
-bool gemm5_ok(Epilogue epi, const GemmArgs& a);
-int gemm5_wgs_per_cu();
-hipError_t launch_gemm5(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t st);
-hipError_t gemm5_init();
-#endif
 
 hipError_t gemm_init() {
     hipError_t e = set_attr_cfg<_Float16, 128, 128, 2, 2, 2>();
@@ -525,9 +619,6 @@ hipError_t gemm_init() {
     if (e == hipSuccess) e = set_attr_cfg<__bf16, 32, 64, 1, 4, 3, 2>();
     if (e == hipSuccess) e = gemm2_init();
     if (e == hipSuccess) e = gemm4_init();
-#ifdef DINO_WITH_GEMM5
-    if (e == hipSuccess) e = gemm5_init();
-#endif
     return e;
 }
 
@@ -569,7 +660,8 @@ static bool plan_note(const char* fmt, ...) {
 }
 template <typename T, int BM, int BN, int WM, int WN, int NST, int KSUB = 1>
 static hipError_t leaf_cfg(Epilogue epi, const GemmArgs& a, hipStream_t st) {
-    if (plan_note("small<%dx%d,w%dx%d,st%d,ks%d>", BM, BN, WM, WN, NST, KSUB)) return BN / WN == 64 || epi != EPI_SWIGLU ? hipSuccess : hipErrorInvalidValue;
+    if (BN / WN != 64 && epi_base(epi) == EPI_SWIGLU) return hipErrorInvalidValue;  // (refused plans leave no text behind: ADVICE r5)
+    if (plan_note("small<%dx%d,w%dx%d,st%d,ks%d>", BM, BN, WM, WN, NST, KSUB)) return hipSuccess;
     return launch_cfg<T, BM, BN, WM, WN, NST, KSUB>(epi, a, st);
 }
 #define DINO_LEAF(CALL, ...) (plan_note(__VA_ARGS__) ? hipSuccess : (CALL))
@@ -601,10 +693,26 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
     // ordinary stores win by 3 % of p50; batch 32: outputs >= 90 MB, non-temporal stores win by 0.7 % of the forward -- profiles/r04_gemm4w.md
     // section 5b); nothing in between was.  Decided ONCE per logical output, at the top-level call: the parts of a split launch (`sub`)
     // inherit it, so one output never leaves under two store policies.
+    const Epilogue eb = epi_base(epi);  // the LN-fold variants are dispatched like the epilogue they specialise
+    const bool ln = eb != epi;
     if (!a.sub) {
         a.nt_out = 0;
-        if (epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU)
-            a.nt_out = (size_t)a.M * (size_t)(epi == EPI_SWIGLU ? a.N / 2 : a.N) * 2 > ((size_t)48 << 20) ? 1 : 0;
+        if (eb == EPI_QKV || eb == EPI_GELU || eb == EPI_SWIGLU)
+            a.nt_out = (size_t)a.M * (size_t)(eb == EPI_SWIGLU ? a.N / 2 : a.N) * 2 > ((size_t)48 << 20) ? 1 : 0;
+        a.clk_slot = DINO_CLK_GEMM_SLOT((int)epi, a.N, a.K);
+        if (ln) {
+            // LN fold: statistics are kept per 64 columns of the LayerNorm's rows, at most LN_MAX_GROUPS of them; the producer writes full
+            // 64-column groups with vector stores from every kernel it may be split over
+            const int hcols = epi == EPI_RESID_LN ? a.N : a.K;
+            if (hcols % 128 != 0 || hcols / LN_GROUP > LN_MAX_GROUPS || (epi == EPI_RESID_LN && a.ldo != a.N)) return hipErrorInvalidValue;
+            if (a.ln_gs == 0) a.ln_gs = ln_stat_slots(hcols);
+            if (a.ln_gs != ln_stat_slots(hcols)) return hipErrorInvalidValue;
+            if (!t_plan_sink) {  // (plan queries carry no pointers)
+                if (!a.stats) return hipErrorInvalidValue;
+                if (epi == EPI_RESID_LN && (!a.ln_gamma || !a.xg || (((size_t)a.ln_gamma | (size_t)a.aux | (size_t)a.bias) & 15))) return hipErrorInvalidValue;
+                if (epi != EPI_RESID_LN && (!a.ln_s || !a.ln_c || (((size_t)a.ln_s | (size_t)a.ln_c) & 15))) return hipErrorInvalidValue;
+            }
+        }
     }
     // staging cursors are 32-bit byte offsets from A and W (dinov2_hip_predict splits batches long before this)
     const size_t lda_ = a.lda ? a.lda : a.K, ldw_ = a.ldw ? a.ldw : a.K;
@@ -617,6 +725,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
     {
         const char* e = getenv("DINOV2_HIP_GEMM_CFG");
         const int c = e ? atoi(e) : -1;
+        if (c >= 0 && t_plan_sink) return hipErrorInvalidValue;  // (plan queries must not launch: ADVICE r5)
         if (c >= 0 && dt == DT_F16) {
             switch (c) {
 #define DINO_SW(n, ...) case n: { static bool once = (hipFuncSetAttribute_all<__VA_ARGS__>(), true); (void)once; return launch_cfg<_Float16, __VA_ARGS__>(epi, a, st); }
@@ -653,26 +762,26 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         }
     }
 #endif
-#ifdef DINO_WITH_GEMM5
-    // G5 (round 5, opt-in build only): 192 x 128 tiles, two independent workgroups per CU (tools/probes/gemm5.hip), when the launch has at
-    // least one tile per resident workgroup (512): one launch for any M and any N % 128 == 0.  Only when DINOV2_HIP_GEMM_GEN=5 asks for it.
-    {
-        const long t5 = (long)(a.N / 128) * ((a.M + 191) / 192);
-        if (!a.small_only && !forced && gen == 5 && gemm5_ok(epi, a) && t5 >= 512) return DINO_LEAF(launch_gemm5(dt, epi, a, st), "gemm5<192x128>");
-    }
-#endif
     // N not a multiple of 256 (ViT-S: 384, 1 152): the persistent kernel takes the leading multiple of 256 columns, the small-tile
     // kernel the remaining ones (two launches; every kernel gives a row the same bits, so the cut is invisible in the results).
     // Only where the persistent part fills the chip; not for the patch / SwiGLU epilogues (row -> token scatter indexed with N,
     // interleaved column pairs).
     {
         const int nrem = a.N % 256, n1 = a.N - nrem;
-        const bool epi_ok = epi == EPI_QKV || epi == EPI_RESID || epi == EPI_GELU || epi == EPI_PLAIN_F32;
+        const bool epi_ok = eb == EPI_QKV || eb == EPI_RESID || eb == EPI_GELU || eb == EPI_PLAIN_F32;
         if (!a.small_only && forced != 128 && nrem != 0 && n1 >= 256 && epi_ok && (a.K / 64) % 2 == 0 &&
             (long)(n1 / 256) * ((a.M + 191) / 192) >= 192) {
-            const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
+            const size_t osz = (eb == EPI_RESID || eb == EPI_PLAIN_F32) ? 4 : 2;
             GemmArgs a1 = a, a2 = a;
             a1.sub = a2.sub = 1;
+            if (epi == EPI_RESID_LN) {  // (row strides of xg and stats come from ldo, which the parts keep)
+                a2.ln_gamma = a.ln_gamma + n1;
+                a2.xg = (char*)a.xg + (size_t)n1 * 2;
+                a2.stats = a.stats + (size_t)(n1 / LN_GROUP) * 2;
+            } else if (ln) {
+                a2.ln_s = a.ln_s + n1;
+                a2.ln_c = a.ln_c + n1;
+            }
             a1.N = n1;
             a1.qcols = a.qcols < n1 ? a.qcols : n1;
             a2.N = nrem;
@@ -690,7 +799,8 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
     constexpr bool split_ok = true;
     // (the patch-embed epilogue maps row -> (image, patch): no row splits for it)
     const bool is_patch = epi == EPI_PATCH;
-    const bool big_ok = !a.small_only && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0;
+    // (the LN-fold epilogues exist in gemm4.hip and in the small-tile kernel, not in gemm2.hip)
+    const bool big_ok = !a.small_only && forced != 128 && a.N % 256 == 0 && (a.K / 64) % 2 == 0 && (!ln || (gen != 2 && gemm4_ok(epi, a)));
     if (big_ok) {
         const int ntn = a.N / 256;
         const long t256 = (long)ntn * ((a.M + 255) / 256), t192 = (long)ntn * ((a.M + 191) / 192);
@@ -703,18 +813,24 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
             best = -1.0;
         } else {
             if (t256 < 192 && costE < best) { plan = 'E'; best = costE; }  // far from filling the chip with big tiles
-            if (split_ok && t192 >= 192 && rnd(t192) * 0.79 < best - 0.02) { plan = 'B'; best = rnd(t192) * 0.79; }
+            if (split_ok && !ln && t192 >= 192 && rnd(t192) * 0.79 < best - 0.02) { plan = 'B'; best = rnd(t192) * 0.79; }
         }
         const long R = t256 / 256;
         const int panels1 = (int)(R * 256 / ntn);
         const int M1 = panels1 * 256;
         GemmArgs a1 = a, a2 = a;
         if (split_ok && !is_patch && forced != 256 && R >= 1 && M1 > 0 && M1 < a.M) {
-            const size_t osz = (epi == EPI_RESID || epi == EPI_PLAIN_F32) ? 4 : 2;
+            const size_t osz = (eb == EPI_RESID || eb == EPI_PLAIN_F32) ? 4 : 2;
             a1.M = M1;
             a2.M = a.M - M1;
             a2.A = (const char*)a.A + (size_t)M1 * lda_ * 2;
             a2.out = (char*)a.out + (size_t)M1 * a.ldo * osz;
+            if (epi == EPI_RESID_LN) {
+                a2.xg = (char*)a.xg + (size_t)M1 * a.ldo * 2;
+                a2.stats = a.stats + (size_t)M1 * a.ln_gs * 2;
+            } else if (ln) {
+                a2.stats = a.stats + (size_t)M1 * a.ln_gs * 2;
+            }
             a1.sub = a2.sub = 1;
             const long tail192 = (long)ntn * ((a2.M + 191) / 192);
             const double costC = (double)R + rnd(tail192) * 0.79;
@@ -724,7 +840,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         }
 #ifdef DINO_GEMM_SWEEP
         if (forced == 192) plan = 'B';
-        if (forced == 129 && !is_patch) return launch_gemm2_128(dt, epi, a, st);
+        if (forced == 129 && !is_patch) return DINO_LEAF(launch_gemm2_128(dt, epi, a, st), "gemm2<128>");
 #endif
         // F: 128-row tiles of the persistent kernel's schedule, one per workgroup, when they give 112 ... 256 workgroups: too few rows to
         // fill the chip with 256- or 192-row tiles, enough columns that 128 x 256 tiles do (ViT-L batch 1 at 518 x 518: QKV 132 tiles
@@ -734,8 +850,8 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         // gives at most one tile per CU (QKV at ViT-L batch 1: 180 tiles of 96 rows instead of 132 of 128; FFN-in 240 instead of 176),
         // for the 2-byte epilogues (profiles/r04_gemm4w.md section 6).  DINOV2_HIP_GEMM_GEN=2 keeps plan F.
         {
-            const bool two_byte = epi == EPI_QKV || epi == EPI_GELU || epi == EPI_SWIGLU;
-            if (two_byte && !forced && gen != 2 && gemm4_ok(epi, a) && (gen == 4 || a.K >= 1024)) {
+            const bool two_byte = eb == EPI_QKV || eb == EPI_GELU || eb == EPI_SWIGLU;
+            if (two_byte && !forced && gen != 2 && gemm4_ok(epi, a) && (gen == 4 || ln || a.K >= 1024)) {
                 int ni = 0;
                 for (int c = 2; c <= 4 && !ni; ++c)
                     if ((long)ntn * ((a.M + 32 * c - 1) / (32 * c)) <= 256) ni = c;
@@ -745,7 +861,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         }
         {
             const long t128r = (long)ntn * ((a.M + 127) / 128);
-            if (!is_patch && !forced && t128r >= 112 && t128r <= 256) return DINO_LEAF(launch_gemm2_128(dt, epi, a, st), "gemm2<128>");
+            if (!is_patch && !ln && !forced && t128r >= 112 && t128r <= 256) return DINO_LEAF(launch_gemm2_128(dt, epi, a, st), "gemm2<128>");
         }
         if (is_patch) plan = (plan == 'E' || t192 < 192) ? 'E' : 'B';  // only the 192-row instantiation exists for this epilogue
         // which generation runs the 256-row / mixed plans: gemm4.hip (four waves, hand-ordered K loop) where it applies, unless
@@ -757,7 +873,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         // DINOV2_HIP_GEMM_GEN=4 forces gemm4.hip wherever it can run (tests).
         // ... and not the residual epilogue at K < 2 048 (attn-out: its read-modify-write burst is 36 % of a tile and eight waves keep more
         // of it in flight: 0.131 against 0.133 ms in the model, four interleaved runs).
-        const bool g4 = gen != 2 && gemm4_ok(epi, a) && (gen == 4 || (a.K >= 1024 && !(epi == EPI_RESID && a.K < 2048)));
+        const bool g4 = ln || (gen != 2 && gemm4_ok(epi, a) && (gen == 4 || (a.K >= 1024 && !(epi == EPI_RESID && a.K < 2048))));
         switch (plan) {
             case 'A': return g4 ? DINO_LEAF(launch_gemm4(dt, epi, a, st), "gemm4<256>") : DINO_LEAF(launch_gemm2(dt, epi, a, st), "gemm2<256>");
             case 'B': return DINO_LEAF(launch_gemm2_192(dt, epi, a, st), "gemm2<192>");
@@ -790,7 +906,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
     //  * the SMALLEST tile that still gives at most one workgroup per CU: every CU that joins shortens everybody's chain (M = 261:
     //    attn-out 9.8 -> 5.7 us, FFN-out 27.3 -> 14.5 on 32 x 64 tiles; QKV 8.9 -> 6.3 on 64 x 64); two workgroups per CU lose again.
     // Nothing about the arithmetic changes -- each output's MFMA chain runs over K in the same order in every configuration.
-    if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256 && epi != EPI_SWIGLU) {
+    if (cfg == 2 && t64 < 256 && (a.K / 64) % 2 == 0 && a.K >= 256 && eb != EPI_SWIGLU) {
         const long t6464 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64), t3264 = (long)((a.M + 31) / 32) * ((a.N + 63) / 64);
         if (t3264 <= 256) return dt == DT_F16 ? leaf_cfg<_Float16, 32, 64, 1, 4, 3, 2>(epi, a, st) : leaf_cfg<__bf16, 32, 64, 1, 4, 3, 2>(epi, a, st);
         if (t6464 <= 256) return dt == DT_F16 ? leaf_cfg<_Float16, 64, 64, 2, 4, 3, 2>(epi, a, st) : leaf_cfg<__bf16, 64, 64, 2, 4, 3, 2>(epi, a, st);

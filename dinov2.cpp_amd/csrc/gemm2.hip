@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DINO_CLK_BEGIN()
     gemm2_body<T, EPI, XREP>(p, smem);
-    DINO_CLK_END(g_clk2, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
+    DINO_CLK_END(g_clk2, p.clk_slot)
 }
 
 // One launch, two tile heights: every block first walks its share of the 256-row tiles of `p` (whole rounds), then its share
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(512) void gemm2_mixed_kernel(GemmArgs p, GemmArgs q
     DINO_CLK_BEGIN()
     gemm2_body<T, EPI, 4>(p, smem);
     gemm2_body<T, EPI, 3>(q, smem);
-    DINO_CLK_END(g_clk2, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
+    DINO_CLK_END(g_clk2, p.clk_slot)
 }
 
 #ifdef DINO_GEMM_PROF
@@ -613,6 +613,7 @@ static hipError_t launch2_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         DINO_L2(EPI_GELU)
         DINO_L2(EPI_SWIGLU)
         DINO_L2(EPI_PLAIN_F32)
+        default: return hipErrorInvalidValue;  // (the LN-fold epilogues live in gemm4.hip and the small-tile kernel)
     }
 #undef DINO_L2
 #ifdef DINO_GEMM_PROF

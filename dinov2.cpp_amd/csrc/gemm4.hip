@@ -114,6 +114,9 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
     using E = Elem<T>;
     using vec4 = typename E::vec4;
     constexpr bool F16 = std::is_same<T, _Float16>::value;
+    // LN fold (kernels.h): LNC = this GEMM consumes T(gamma x) and applies the LayerNorm in its epilogue; EB = the epilogue it specialises
+    constexpr bool LNC = EPI == EPI_QKV_LN || EPI == EPI_GELU_LN || EPI == EPI_SWIGLU_LN;
+    constexpr int EB = EPI == EPI_RESID_LN ? EPI_RESID : EPI == EPI_QKV_LN ? EPI_QKV : EPI == EPI_GELU_LN ? EPI_GELU : EPI == EPI_SWIGLU_LN ? EPI_SWIGLU : EPI;
     constexpr int BM = 32 * NI, BN = 256;
     constexpr int NP = NI + 8;         // LDS-DMA pieces per wave and K-tile: NI of X, 8 of W
     // staging slots at m = SP k: one per 8 MFMA indices for the tall tiles (a K-tile's staging spans one K-tile time); one per 4 for the
@@ -165,8 +168,12 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
     auto piece_off = [&](int pc, int m0, int n0) -> unsigned {
         const bool isw = pc >= 2 * NI || (pc & 1);
         const int rb = pc >= 2 * NI ? pc - NI : pc >> 1;
-        const int r = (isw ? 64 : 8 * NI) * wid + 8 * rb + (lane >> 3);
-        const int ch = (lane & 7) ^ ((r >> 1) & 7);
+        // (LN consumers: their epilogue needs the registers that the loop-invariant parts of these sixteen offsets would otherwise occupy
+        //  across the whole tile loop -- they spilled, and were reloaded from scratch inside the K loop; recomputed at the tile change instead)
+        int pl = lane;
+        if constexpr (LNC) asm volatile("" : "+v"(pl));
+        const int r = (isw ? 64 : 8 * NI) * wid + 8 * rb + (pl >> 3);
+        const int ch = (pl & 7) ^ ((r >> 1) & 7);
         if (isw) return (unsigned)(n0 + r) * ldw2 + ch * 16;
         int gm = m0 + r;
         gm = gm < M ? gm : M - 1;
@@ -279,6 +286,23 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
     using TF = std::integral_constant<bool, false>;
     auto nop = [] {};
 
+    // LN consumers: st_r / st_n[h] = the LayerNorm coefficients (r, -mean r) of row 64 h + lane of this wave's 16 NI rows of the CURRENT tile.
+    // They are requested one tile ahead -- for the first tile here, ahead of the staging (the first K-tile's wait covers them), for the
+    // others from inside the previous tile's epilogue -- and handed to the lanes that need them through the wave's LDS slice at the
+    // start of the epilogue.
+    constexpr int LNH = !LNC ? 0 : NI > 4 ? 2 : 1;
+    float st_r[LNH ? LNH : 1], st_n[LNH ? LNH : 1];
+    const int ln_gs = p.ln_gs;  // slots per row of the statistics buffer: 12 or 24
+    const float ln_inv_h = 1.0f / (float)K;
+    auto ln_row_of = [&](int m0_, int h) {
+        int ll = lane;
+        asm volatile("" : "+v"(ll));  // (opaque: nothing of this is to be hoisted out of the persistent tile loop)
+        int rl = h * 64 + ll;
+        rl = rl < 16 * NI ? rl : 16 * NI - 1;
+        const int row = m0_ + wr * (16 * NI) + rl;
+        return row < M ? row : M - 1;
+    };
+
     if (bidx < chunkn) {
         int pm0, pn0;
         tile_mn(chunk0 + bidx, pm0, pn0);
@@ -286,6 +310,14 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
         for (int pc = 0; pc < NP; ++pc) so[pc] = piece_off(pc, pm0, pn0);
         // every wave has left the previous body's epilogue slices and buffers (gemm4_mixed_kernel runs two bodies back to back)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LnRaw lraw[LNH ? LNH : 1], lraw1[LNH ? LNH : 1];  // (both halves of the rows' slots at once: one round trip, under the staging)
+        if constexpr (LNC) {
+#pragma unroll
+            for (int h = 0; h < LNH; ++h) {
+                ln_row_load<0>(p.stats, ln_row_of(pm0, h), ln_gs, lraw[h]);
+                if (ln_gs > 12) ln_row_load<1>(p.stats, ln_row_of(pm0, h), ln_gs, lraw1[h]);
+            }
+        }
         // K-tile 0 whole, K-tile 1's first NPOST pieces (its last ones go out before barrier A of K-tile 0, like everywhere else)
         static_for<NP>([&so, &ldsx, &ldsw, Ab, Wb](auto pcc) { DINO4_PIECE(decltype(pcc)::value, 0, 0) });
         static_for<NPOST>([&so, &ldsx, &ldsw, Ab, Wb](auto pcc) { DINO4_PIECE(decltype(pcc)::value, 1, 1) });
@@ -297,6 +329,15 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
             else DINO4_DSR(Px[q - 8], xa[0], (q - 8) * 2048);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (LNC) {
+#pragma unroll
+            for (int h = 0; h < LNH; ++h) {
+                LnAcc la;
+                ln_row_add<0>(lraw[h], la);
+                if (ln_gs > 12) ln_row_add<1>(lraw1[h], la);
+                ln_row_finish(la, ln_inv_h, p.ln_eps, st_r[h], st_n[h]);
+            }
+        }
     }
     for (int tix = bidx; tix < chunkn; tix += nb_x) {
         int m0, n0;
@@ -316,16 +357,47 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
         ktile(T0{}, TF{}, nk - 1, true,
               [&] {
                   if (has_next) {
+                      if constexpr (LNC) {
+                          // (LN consumers keep none of piece_off's loop-invariant parts in registers: inside the matrix, the next tile's
+                          //  offsets are this tile's plus two scalars; only a tile on the M edge -- clamped rows -- takes the full computation)
+                          if (m0 + BM <= M && nm0 + BM <= M) {
+                              const unsigned dx = (unsigned)(nm0 - m0) * lda2, dw = (unsigned)(nn0 - n0) * ldw2;
 #pragma unroll
-                      for (int pc = 0; pc < NP; ++pc) so[pc] = piece_off(pc, nm0, nn0);
+                              for (int pc = 0; pc < NP; ++pc) so[pc] += (pc >= 2 * NI || (pc & 1)) ? dw : dx;
+                          } else {
+#pragma unroll
+                              for (int pc = 0; pc < NP; ++pc) so[pc] = piece_off(pc, nm0, nn0);
+                          }
+                      } else {
+#pragma unroll
+                          for (int pc = 0; pc < NP; ++pc) so[pc] = piece_off(pc, nm0, nn0);
+                      }
                   }
               },
               0, has_next, true);
-        ktile(T1{}, TF{}, 0, has_next, nop, 1, has_next, has_next);
+        // LN consumers: the wave's 128 columns of s[n] (lanes 0 .. 31, four each) and c[n] (lanes 32 .. 63), requested under the last K-tile.
+        // The epilogue's passes fetch their 16-column blocks from these lanes (ds_bpermute): a global load inside a pass would have to
+        // wait for the previous pass's STORES to retire (gfx950 retires loads and stores through one in-order counter) -- measured: QKV
+        // + 15 %, FFN-in + 18 % with per-block loads.
+        float4 lnsc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (LNC) {
+            int ll = lane;
+            asm volatile("" : "+v"(ll));
+            lnsc = *(const float4*)((ll < 32 ? p.ln_s : p.ln_c) + n0 + wc * 128 + 4 * (ll & 31));
+        }
+        // (LN consumers read the next tile's first fragments AFTER the epilogue, not under this K-tile: their epilogue has no 64 registers to
+        //  carry them in, and a fragment the compiler spills is spilled right behind the asm ds_read that requests it -- before the data has
+        //  arrived.  Round 6: that is what happened to Pw[3] of EPI_QKV_LN, and every tile lost its first k-step in columns 48 .. 63.)
+        ktile(T1{}, TF{}, 0, has_next, nop, 1, has_next, has_next && !LNC);
         // The compiler's hazard recogniser cannot see into the asm statements: make the last MFMAs' results architecturally visible to the
         // v_accvgpr_read of the epilogue by hand (16x16x32: 8 passes; the epilogue starts with acc[0][0], written 127 MFMAs ago, but nothing in
         // the source guarantees that order) -- 24 idle cycles per tile
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        // ... and pin every accumulator read BEHIND those wait states: a v_accvgpr_read is an ordinary instruction with a data dependence on
+        // the LAST asm statement that wrote its register only, so the scheduler is free to hoist it into the K loop's stream, right behind
+        // that MFMA (round 6: it did, in the EPI_QKV_LN instantiation -- columns 48 .. 63 of every first column group came out wrong,
+        // timing-dependent).  Volatile statements keep their order, and each of these redefines its accumulator after the s_nop.
+        static_for<NI * 8>([&acc](auto ic) { asm volatile("" : "+a"(acc[decltype(ic)::value / 8][decltype(ic)::value % 8])); });
         DINO4_GP(0)
 
         // ---- epilogue (gemm2.hip's, per 64-column group cg of the wave's 128 columns): each wave transposes its result through a private
@@ -337,43 +409,111 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
         const int er = el & 15, eq = el >> 4;
         char* const ep = smem + 131072 + wid * 8192;
         const int mbase = m0 + wr * (16 * NI);
+        // LN consumers: the coefficients of the CURRENT tile move aside (st_r / st_n are refilled for the next tile during this epilogue);
+        // every pass fetches those of its four row blocks from the lanes that hold them (ds_bpermute: no LDS storage involved)
+        float cu_r[LNH ? LNH : 1], cu_n[LNH ? LNH : 1];
+        if constexpr (LNC) {
+#pragma unroll
+            for (int h = 0; h < LNH; ++h) {
+                cu_r[h] = st_r[h];
+                cu_n[h] = st_n[h];
+            }
+        }
 #define DINO4_ACC(Q_, B_, I_, J_) acc[((Q_)*4 + (I_)) < NI ? ((Q_)*4 + (I_)) : 0][cg * 4 + (B_)*2 + (J_)]  /* (the clamp only ever acts in dead code) */
 #pragma unroll
         for (int cg = 0; cg < 2; ++cg) {
             const int nw0 = n0 + wc * 128 + cg * 64;  // first column of this 64-column group
             const int ncol = nw0 + 4 * eq;            // + 32 b + 16 j: this lane's four consecutive columns of block (b, j)
+            // bs: the additive per-column term, fetched ahead for the whole column group.  (LN consumers fetch theirs -- c[n], which contains
+            // the bias, and s[n] -- per 16-column block inside the passes: their epilogue has no registers to park 32 values in)
             float4 bs[2][2];
+            if constexpr (!LNC && EPI != EPI_RESID_LN) {
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+                for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    bs[b][j] = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int j = 0; j < 2; ++j)
+                        bs[b][j] = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            // LN consumers: this column group's s[n] / c[n] blocks from the lanes that hold them (one batch of ds_bpermute per column group:
+            // with one wave per SIMD every dependent LDS round trip inside a pass is exposed)
+            float4 lsv[LNC ? 2 : 1][2], lcv[LNC ? 2 : 1][2];
+            if constexpr (LNC) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int f = cg * 16 + b * 8 + j * 4 + eq;  // this lane's float4 of block (b, j), as an index into the wave's 128 columns
+                        lsv[b][j] = make_float4(__shfl(lnsc.x, f), __shfl(lnsc.y, f), __shfl(lnsc.z, f), __shfl(lnsc.w, f));
+                        lcv[b][j] = make_float4(__shfl(lnsc.x, 32 + f), __shfl(lnsc.y, 32 + f), __shfl(lnsc.z, 32 + f), __shfl(lnsc.w, 32 + f));
+                    }
+            }
+            // LN consumers with a next tile: request the partial sums of its rows 64 cg + lane now, turn them into coefficients when this
+            // column group is done (st_r / st_n of the current tile were handed out above)
+            LnRaw lraw;
+            LnAcc lacc;
+            const bool ln_next = LNC && cg < LNH && has_next;
+            if constexpr (LNC) {
+                if (ln_next) ln_row_load<0>(p.stats, ln_row_of(nm0, cg), ln_gs, lraw);
+            }
 
-            if constexpr (EPI == EPI_QKV || EPI == EPI_GELU || EPI == EPI_SWIGLU) {
+            if constexpr (EB == EPI_QKV || EB == EPI_GELU || EB == EPI_SWIGLU) {
                 // 2-byte outputs: two passes (token halves) of 64 rows x 64 columns (SwiGLU: x 32)
-                const float qs = (EPI == EPI_QKV && nw0 < p.qcols) ? p.qscale : 1.0f;
-                constexpr int BN_ = EPI == EPI_SWIGLU ? 1 : 2;
+                const float qs = (EB == EPI_QKV && nw0 < p.qcols) ? p.qscale : 1.0f;
+                constexpr int BN_ = EB == EPI_SWIGLU ? 1 : 2;
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
+                    if constexpr (LNC) {
+                        if (q == 1 && ln_next) {  // between the token halves: first twelve groups in, the rest requested
+                            ln_row_add<0>(lraw, lacc);
+                            if (ln_gs > 12) ln_row_load<1>(p.stats, ln_row_of(nm0, cg), ln_gs, lraw);
+                        }
+                    }
                     if (q * 4 >= NI) continue;  // (tiles of at most 128 rows: one token half)
+                    float lnr[LNC ? 4 : 1], lnn[LNC ? 4 : 1];  // rows 64 q + 16 i + (lane & 15): held by lane 16 i + (lane & 15) as its row-half q
+                    if constexpr (LNC) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            lnr[i] = __shfl(cu_r[q < LNH ? q : 0], 16 * i + er);
+                            lnn[i] = __shfl(cu_n[q < LNH ? q : 0], 16 * i + er);
+                        }
+                    }
 #pragma unroll
                     for (int b = 0; b < BN_; ++b)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const float bb[4] = {bs[b][j].x, bs[b][j].y, bs[b][j].z, bs[b][j].w};
-                            const float b2[4] = {bs[1][j].x, bs[1][j].y, bs[1][j].z, bs[1][j].w};
+                            float4 bbv, b2v, sbv = make_float4(0.f, 0.f, 0.f, 0.f), s2v = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if constexpr (LNC) {
+                                sbv = lsv[b][j];
+                                bbv = lcv[b][j];
+                                b2v = lcv[1][j];
+                                s2v = lsv[1][j];
+                            } else {
+                                bbv = bs[b][j];
+                                b2v = bs[1][j];
+                            }
+                            const float bb[4] = {bbv.x, bbv.y, bbv.z, bbv.w};
+                            const float b2[4] = {b2v.x, b2v.y, b2v.z, b2v.w};
+                            const float sb[4] = {sbv.x, sbv.y, sbv.z, sbv.w};
+                            const float s2[4] = {s2v.x, s2v.y, s2v.z, s2v.w};
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 if (q * 4 + i >= NI) continue;  // shorter tiles: fewer 16-token blocks
+                                const int ir = i;  // (index of this block's row coefficients)
                                 vec4 o;
-                                if constexpr (EPI == EPI_GELU) {
+                                if constexpr (EB == EPI_GELU) {
                                     // ggml semantics: y = table[f16(x)], table[h] = f16(gelu_tanh(f32(h))); two columns per instruction
                                     // (v_pk_*_f32: IEEE results identical to the scalar ops of gemm.hip, so the kernels agree bit for bit)
                                     typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
                                     for (int e2 = 0; e2 < 2; ++e2) {
                                         f32x2 v = {DINO4_ACC(q, b, i, j)[2 * e2], DINO4_ACC(q, b, i, j)[2 * e2 + 1]};
-                                        v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
+                                        if constexpr (LNC) {  // r (acc - mean s[n]) + c[n] as two fused multiply-adds per column (v_pk_fma_f32)
+                                            const f32x2 d = __builtin_elementwise_fma(f32x2{lnn[LNC ? ir : 0], lnn[LNC ? ir : 0]}, f32x2{sb[2 * e2], sb[2 * e2 + 1]},
+                                                                                      f32x2{bb[2 * e2], bb[2 * e2 + 1]});
+                                            v = __builtin_elementwise_fma(f32x2{lnr[LNC ? ir : 0], lnr[LNC ? ir : 0]}, v, d);
+                                        } else {
+                                            v += f32x2{bb[2 * e2], bb[2 * e2 + 1]};
+                                        }
                                         asm("" : "+v"(v));  // f32 sums first (no v_fma_mix fusion), then the f16 rounding
                                         typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
                                         const f32x2 xr = __builtin_convertvector(__builtin_convertvector(v, f16x2), f32x2);
@@ -388,15 +528,19 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                                 } else {
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
-                                        float v = DINO4_ACC(q, b, i, j)[e] + bb[e];
+                                        float v;
+                                        if constexpr (LNC) v = __builtin_fmaf(lnr[LNC ? ir : 0], DINO4_ACC(q, b, i, j)[e], __builtin_fmaf(lnn[LNC ? ir : 0], sb[e], bb[e]));
+                                        else v = DINO4_ACC(q, b, i, j)[e] + bb[e];
                                         asm("" : "+v"(v));  // a real f32 sum: no "add, then round" fusion into v_fma_mixlo_f16
-                                        if constexpr (EPI == EPI_QKV) {
+                                        if constexpr (EB == EPI_QKV) {
                                             float vq = v * qs;
                                             asm("" : "+v"(vq));
                                             o[e] = E::from_f32(vq);
                                         } else {
                                             // EPI_SWIGLU: W rows interleaved in 32-blocks: column half 0 holds x1[32 units], half 1 x2 of the same units
-                                            const float h2 = DINO4_ACC(q, 1, i, j)[e] + b2[e];
+                                            float h2;
+                                            if constexpr (LNC) h2 = __builtin_fmaf(lnr[LNC ? ir : 0], DINO4_ACC(q, 1, i, j)[e], __builtin_fmaf(lnn[LNC ? ir : 0], s2[e], b2[e]));
+                                            else h2 = DINO4_ACC(q, 1, i, j)[e] + b2[e];
                                             float sg = v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)) * h2;  // silu(x1) * x2
                                             asm("" : "+v"(sg));
                                             o[e] = E::from_f32(sg);
@@ -409,7 +553,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                             }
                         }
                     __builtin_amdgcn_wave_barrier();
-                    if constexpr (EPI == EPI_SWIGLU) {
+                    if constexpr (EB == EPI_SWIGLU) {
                         const int hid0 = (nw0 >> 6) * 32;  // 32 hidden units = 64 B per row: 4 lanes per row
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
@@ -434,6 +578,12 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                 }
             } else {
                 // (4-byte outputs are handled after this loop: their passes are software-pipelined across both column groups)
+            }
+            if constexpr (LNC) {
+                if (ln_next) {
+                    if (ln_gs > 12) ln_row_add<1>(lraw, lacc);
+                    ln_row_finish(lacc, ln_inv_h, p.ln_eps, st_r[cg < LNH ? cg : 0], st_n[cg < LNH ? cg : 0]);
+                }
             }
         }
         if constexpr (EPI == EPI_RESID || EPI == EPI_PLAIN_F32) {
@@ -499,7 +649,130 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if constexpr (EPI == EPI_RESID_LN) {
+            // The residual epilogue that also feeds the LayerNorm behind it (LN fold, kernels.h): x += ls (acc + bias) as above, plus the
+            // next GEMM's operand xg = T(x gamma) and, per row, (sum, sum of squares) of x over this 64-column group.  Eight passes (column
+            // group cg, token half q, 32-row half ih) of 32 rows x 64 columns -- 256 B of f32 per row, so that ONE pass holds a whole
+            // statistics group of its rows: 16 lanes per row, reduced with row-local DPP in the fixed pairwise order of ln_leaf4 (4 -> 8 ->
+            // 16 -> 32 -> 64 columns; the small-tile kernel produces the same bits), and xg leaves as whole 128-byte lines.  LDS slice image:
+            // 32 rows x 256 B, 16-byte slot s of row r at s ^ (r & 15).  Residual rows are requested PF passes ahead, as above.
+            constexpr int PF = 2;
+            float4 add[8][8];
+            auto pass_of = [&](int ps8, int& cg, int& q, int& ih) {
+                cg = ps8 >> 2;
+                q = (ps8 >> 1) & 1;
+                ih = ps8 & 1;
+            };
+            auto pass_live = [&](int ps8) {
+                const int q = (ps8 >> 1) & 1, ih = ps8 & 1;
+                return q * 4 + ih * 2 < NI;
+            };
+            auto issue_loads = [&](int ps8) {
+                int cg, q, ih;
+                pass_of(ps8, cg, q, ih);
+                const int nb = n0 + wc * 128 + cg * 64 + (el & 15) * 4;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    int m = mbase + q * 64 + ih * 32 + it * 4 + (el >> 4);
+                    m = m < M ? m : M - 1;
+                    add[ps8][it] = *(const float4*)((const float*)p.out + (size_t)m * p.ldo + nb);
+                }
+            };
+            // (NI = 6: passes with q = 1, ih = 1 do not exist; the pipeline simply skips them)
+            int issued = 0;
+#pragma unroll
+            for (int ps8 = 0; ps8 < 8; ++ps8)
+                if (pass_live(ps8) && issued < PF) {
+                    issue_loads(ps8);
+                    ++issued;
+                }
+#pragma unroll
+            for (int ps8 = 0; ps8 < 8; ++ps8) {
+                if (!pass_live(ps8)) continue;
+                int cg, q, ih;
+                pass_of(ps8, cg, q, ih);
+                asm volatile("" : "+v"(el));
+                const int ncol = n0 + wc * 128 + cg * 64 + 4 * (el >> 4);   // acc layout: + 32 b + 16 j
+                const int nb = n0 + wc * 128 + cg * 64 + (el & 15) * 4;    // line layout: this lane's four columns of the 64
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float4 ls = *(const float4*)(p.aux + ncol + b * 32 + j * 16);
+                        const float4 b4 = p.bias ? *(const float4*)(p.bias + ncol + b * 32 + j * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int ii = 0; ii < 2; ++ii) {
+                            if (q * 4 + ih * 2 + ii >= NI) continue;
+                            const int row = ii * 16 + (el & 15);
+                            const int slot = (b * 8 + j * 4 + (el >> 4)) ^ (row & 15);
+                            const f32x4 a = DINO4_ACC(q, b, ih * 2 + ii, j);
+                            *(float4*)(ep + row * 256 + slot * 16) =
+                                make_float4((a[0] + b4.x) * ls.x, (a[1] + b4.y) * ls.y, (a[2] + b4.z) * ls.z, (a[3] + b4.w) * ls.w);
+                        }
+                    }
+                const float4 gam = *(const float4*)(p.ln_gamma + nb);
+                {  // the loads of the pass PF live passes ahead, before this pass's stores
+                    int ahead = 0;
+#pragma unroll
+                    for (int nx = ps8 + 1; nx < 8; ++nx)
+                        if (pass_live(nx) && ++ahead == PF) issue_loads(nx);
+                }
+                __builtin_amdgcn_wave_barrier();
+                float ssum = 0.f, ssq = 0.f;  // this lane's row of the pass: lanes (el & 15) < 8 own row 4 (el & 15) + (el >> 4)
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    const int row = it * 4 + (el >> 4), slot = el & 15;
+                    float4 v = *(const float4*)(ep + row * 256 + ((slot ^ (row & 15)) << 4));
+                    v = make_float4(v.x + add[ps8][it].x, v.y + add[ps8][it].y, v.z + add[ps8][it].z, v.w + add[ps8][it].w);
+                    const int rl = q * 64 + ih * 32 + row;
+                    const int m = mbase + rl;
+                    const bool live = m < M && (NI == 8 || rl < 16 * NI);
+                    if (live) *(float4*)((float*)p.out + (size_t)m * p.ldo + nb) = v;
+                    vec4 og;
+                    {
+                        float g0 = v.x * gam.x, g1 = v.y * gam.y, g2 = v.z * gam.z, g3 = v.w * gam.w;
+                        asm("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));  // f32 products first, then the rounding
+                        og[0] = E::from_f32(g0);
+                        og[1] = E::from_f32(g1);
+                        og[2] = E::from_f32(g2);
+                        og[3] = E::from_f32(g3);
+                    }
+                    if (live) *(vec4*)((T*)p.xg + (size_t)m * p.ldo + nb) = og;
+                    float s4, q4;
+                    ln_leaf4(v.x, v.y, v.z, v.w, s4, q4);
+                    s4 += dpp_f32<0xB1>(s4);   // 8 columns  (quad_perm [1,0,3,2])
+                    q4 += dpp_f32<0xB1>(q4);
+                    s4 += dpp_f32<0x4E>(s4);   // 16         (quad_perm [2,3,0,1])
+                    q4 += dpp_f32<0x4E>(q4);
+                    s4 += dpp_f32<0x141>(s4);  // 32         (row_half_mirror)
+                    q4 += dpp_f32<0x141>(q4);
+                    s4 += dpp_f32<0x140>(s4);  // 64         (row_mirror)
+                    q4 += dpp_f32<0x140>(q4);
+                    if ((el & 15) == it) {
+                        ssum = s4;
+                        ssq = q4;
+                    }
+                }
+                {
+                    const int rl = q * 64 + ih * 32 + (el & 15) * 4 + (el >> 4);
+                    const int m = mbase + rl;
+                    if ((el & 15) < 8 && m < M && (NI == 8 || rl < 16 * NI))
+                        *(float2*)(p.stats + ((size_t)m * p.ln_gs + ((n0 + wc * 128 + cg * 64) >> 6)) * 2) = make_float2(ssum, ssq);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
 #undef DINO4_ACC
+        if constexpr (LNC) {
+            if (has_next) {  // the next tile's K-tile 0 sits in buffer 0 since barrier B of the last K-tile
+                static_for<8 + NI>([&Px, &Pw, &xa, &wa](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    if constexpr (q < 8) DINO4_DSR(Pw[q], wa[0], q * 2048);
+                    else DINO4_DSR(Px[q - 8], xa[0], (q - 8) * 2048);
+                });
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        }
         DINO4_GP(1)
         DINO4_GP_TILE
     }  // persistent tile loop
@@ -512,7 +785,7 @@ __global__ __launch_bounds__(256) void gemm4_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     DINO_CLK_BEGIN()
     gemm4_body<T, EPI, NI>(p, smem);
-    DINO_CLK_END(g_clk4, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
+    DINO_CLK_END(g_clk4, p.clk_slot)
 }
 
 // One launch, two tile heights (gemm2_mixed_kernel's plan): every workgroup first walks its share of the 256-row tiles of `p` (whole
@@ -534,7 +807,7 @@ __global__ __launch_bounds__(256) void gemm4_mixed_kernel(GemmArgs p, GemmArgs q
         gemm4_body<T, EPI, 8>(p, smem);
         gemm4_body<T, EPI, 6>(q, smem);
     }
-    DINO_CLK_END(g_clk4, DINO_CLK_GEMM_SLOT(EPI, p.N, p.K))
+    DINO_CLK_END(g_clk4, p.clk_slot)
 }
 
 constexpr size_t G4_LDS = 163840;
@@ -568,6 +841,10 @@ static hipError_t launch4_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
         DINO_L4(EPI_GELU)
         DINO_L4(EPI_SWIGLU)
         DINO_L4(EPI_PLAIN_F32)
+        DINO_L4(EPI_RESID_LN)
+        DINO_L4(EPI_QKV_LN)
+        DINO_L4(EPI_GELU_LN)
+        DINO_L4(EPI_SWIGLU_LN)
         default: return hipErrorInvalidValue;
     }
 #undef DINO_L4
@@ -590,6 +867,10 @@ static hipError_t launch4_mixed_t(Epilogue epi, const GemmArgs& a, const GemmArg
         DINO_LM4(EPI_GELU)
         DINO_LM4(EPI_SWIGLU)
         DINO_LM4(EPI_PLAIN_F32)
+        DINO_LM4(EPI_RESID_LN)
+        DINO_LM4(EPI_QKV_LN)
+        DINO_LM4(EPI_GELU_LN)
+        DINO_LM4(EPI_SWIGLU_LN)
         default: return hipErrorInvalidValue;
     }
 #undef DINO_LM4
@@ -623,6 +904,9 @@ static hipError_t launch4_short_t(Epilogue epi, const GemmArgs& a, hipStream_t s
         case EPI_QKV: hipLaunchKernelGGL((gemm4_kernel<T, EPI_QKV, NI>), grid, block, G4_LDS, st, a); break;
         case EPI_GELU: hipLaunchKernelGGL((gemm4_kernel<T, EPI_GELU, NI>), grid, block, G4_LDS, st, a); break;
         case EPI_SWIGLU: hipLaunchKernelGGL((gemm4_kernel<T, EPI_SWIGLU, NI>), grid, block, G4_LDS, st, a); break;
+        case EPI_QKV_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_QKV_LN, NI>), grid, block, G4_LDS, st, a); break;
+        case EPI_GELU_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_GELU_LN, NI>), grid, block, G4_LDS, st, a); break;
+        case EPI_SWIGLU_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_SWIGLU_LN, NI>), grid, block, G4_LDS, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -638,6 +922,9 @@ static hipError_t attr4_short_t() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_QKV, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_GELU, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_SWIGLU, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_QKV_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_GELU_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_SWIGLU_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
     return e;
 }
 
@@ -654,6 +941,10 @@ static hipError_t attr4_t() {
     DINO_A4(EPI_GELU)
     DINO_A4(EPI_SWIGLU)
     DINO_A4(EPI_PLAIN_F32)
+    DINO_A4(EPI_RESID_LN)
+    DINO_A4(EPI_QKV_LN)
+    DINO_A4(EPI_GELU_LN)
+    DINO_A4(EPI_SWIGLU_LN)
 #undef DINO_A4
     return e;
 }

@@ -16,8 +16,26 @@ enum Epilogue : int {
     EPI_RESID = 2,   // x[m, n] += ls[n] * (acc + bias[n])                         (f32 in/out)
     EPI_GELU = 3,    // out[m, n] = T(f16(gelu_tanh(f16(acc + bias[n]))))          (T out; ggml f16-LUT contract)
     EPI_SWIGLU = 4,  // out[m, j] = T(silu(h1) * h2), rows of W interleaved in 32-blocks x1|x2 (T out, width N/2)
-    EPI_PLAIN_F32 = 5  // out[m, n] = acc + bias[n]                                (f32 out; tests / head)
+    EPI_PLAIN_F32 = 5,  // out[m, n] = acc + bias[n]                                (f32 out; tests / head)
+    // ---- LayerNorm folded into the GEMMs on either side of it ("LN fold"; replaces ggml_norm + mul + add,
+    // /root/reference/dinov2.cpp:694-700, 722-728, as separate launches).  With LN(x) = gamma (x - mu) r + beta feeding a weight matmul,
+    //     sum_k LN(x)[m,k] W[n,k] + b[n]  =  r_m (sum_k (gamma_k x[m,k]) W[n,k]  -  mu_m s[n]) + c[n],
+    //     s[n] = sum_k gamma_k W[n,k],   c[n] = b[n] + sum_k beta_k W[n,k]           (both computed once, at load time)
+    // so the PRODUCER of x (the residual epilogue) also writes the operand T(gamma x) and per-row partial sums, and the CONSUMER
+    // (QKV / FFN-in) applies r_m, mu_m, s, c in its epilogue.
+    EPI_RESID_LN = 6,   // EPI_RESID, plus: xg[m, n] = T(x[m, n] * ln_gamma[n]);  stats[m][n / 64] = (sum, sum of squares) of x[m, 64 g .. 64 g + 63]
+    EPI_QKV_LN = 7,     // v = r_m * (acc - mu_m * ln_s[n]) + ln_c[n], then as EPI_QKV / EPI_GELU / EPI_SWIGLU with v in place of acc + bias[n]
+    EPI_GELU_LN = 8,
+    EPI_SWIGLU_LN = 9
 };
+// the epilogue an LN-fold variant specialises (dispatch decisions depend on this one only)
+inline Epilogue epi_base(Epilogue e) {
+    return e == EPI_RESID_LN ? EPI_RESID : e == EPI_QKV_LN ? EPI_QKV : e == EPI_GELU_LN ? EPI_GELU : e == EPI_SWIGLU_LN ? EPI_SWIGLU : e;
+}
+inline bool epi_ln_consumer(Epilogue e) { return e == EPI_QKV_LN || e == EPI_GELU_LN || e == EPI_SWIGLU_LN; }
+constexpr int LN_GROUP = 64;      // columns per partial-sum group of EPI_RESID_LN's row statistics
+constexpr int LN_MAX_GROUPS = 24; // hidden sizes up to 1 536 (ViT-g); larger models keep the LayerNorm launches
+inline int ln_stat_slots(int hidden) { return hidden / LN_GROUP <= 12 ? 12 : 24; }  // slots per row of the statistics buffer (device_types.h, ln_row_load)
 
 struct GemmArgs {
     const void* A;      // [M, K]  T, row-major, K % 64 == 0
@@ -34,11 +52,19 @@ struct GemmArgs {
     int small_only;     // launch_gemm internal: this is the tail of a split launch, use the small-tile kernel
     int nt_out;         // launch_gemm internal: 2-byte outputs leave with non-temporal stores (set when the output is larger than the L2s)
     int sub;            // launch_gemm internal: one part of a split launch (inherits nt_out from the whole)
-    unsigned* sched;    // only read by the opt-in generation 5 (tools/probes/gemm5.hip): its ticket counters, GEMM_SCHED_BYTES of
-                        // zero-initialised device memory that no concurrently running launch shares; nullptr = a per-device default
+    int clk_slot;       // launch_gemm internal: the clock-probe slot of the LOGICAL launch (device_types.h), decided before any split
+    // ---- LN fold (EPI_RESID_LN and the *_LN consumers).  Row statistics: stats[(m * ln_gs + g) * 2 + {0, 1}] = sum / sum of squares
+    // of x[m, 64 g .. 64 g + 63] (f32, a fixed pairwise tree over the 64 columns: every kernel produces the same bits); ln_gs = slots per
+    // row = ln_stat_slots(hidden): 12 or 24, the slots past hidden / 64 zero (set once, never written)
+    int ln_gs;
+    const float* ln_gamma;  // EPI_RESID_LN: weight [N] of the LayerNorm that FOLLOWS this residual update
+    void* xg;               // EPI_RESID_LN: [M, N] T, T(x * ln_gamma) -- the consumer's A operand
+    float* stats;           // EPI_RESID_LN: written ([M][N / 64][2]); consumers: read ([M][K / 64][2])
+    const float* ln_s;      // consumers: s[n] = sum_k gamma_k W[n, k]
+    const float* ln_c;      // consumers: c[n] = bias[n] + sum_k beta_k W[n, k]   (`bias` is not read)
+    float ln_eps;           // consumers: LayerNorm epsilon
 };
 
-constexpr size_t GEMM_SCHED_BYTES = 8 * 32 * sizeof(unsigned);
 hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a, hipStream_t stream);
 // must be called once per device before the first launch_gemm (raises the dynamic-LDS limit)
 hipError_t gemm_init();
@@ -50,7 +76,7 @@ hipError_t gemm_plan_describe(DType dt, Epilogue epi, const GemmArgs& a, char* o
 // Testing aids that used to be read from the environment on every launch: read ONCE (first use), changed afterwards only through
 // tune_set (dinov2_hip_op_set_tuning, include/dinov2_hip_ops.h).  0 = the library's own choice.
 enum TuneKey : int {
-    TUNE_GEMM_GEN = 0,   // DINOV2_HIP_GEMM_GEN: 2 | 4 | 5 = force that generation of the persistent GEMM wherever it can run
+    TUNE_GEMM_GEN = 0,   // DINOV2_HIP_GEMM_GEN: 2 | 4 = force that generation of the persistent GEMM wherever it can run
     TUNE_GEMM_TILE = 1,  // DINOV2_HIP_GEMM_TILE: 128 | 256 (tuning builds: 129 | 192)
     TUNE_ATTN_V = 2,     // DINOV2_HIP_ATTN_V: 1 .. 4
     TUNE_ATTN_NWV = 3,   // DINOV2_HIP_ATTN_NWV: 2 | 3 | 4
@@ -65,6 +91,12 @@ hipError_t launch_layernorm(DType dt, const float* x, const float* w, const floa
 // same, f32 output (final layernorm)
 hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, float* y, int rows, int H, float eps,
                                 hipStream_t stream);
+// LN fold (EPI_RESID_LN): what the residual epilogue leaves behind, computed from a residual stream no GEMM has written (before layer 0):
+// xg [rows, H] T = T(x gamma), stats [rows][gs][2] = (sum, sum of squares) per 64 columns in the producers' summation order (gs = ln_stat_slots(H))
+hipError_t launch_ln_prepare(DType dt, const float* x, const float* gamma, void* xg, float* stats, int gs, int rows, int H, hipStream_t stream);
+// load time: s[n] = sum_k gamma[k] W[n, k], c[n] = bias[n] + sum_k beta[k] W[n, k]   (W [N, K] T, dense; bias may be nullptr)
+hipError_t launch_ln_fold_vectors(DType dt, const void* W, const float* bias, const float* gamma, const float* beta, float* s, float* c, int N, int K,
+                                  hipStream_t stream);
 // fused multi-head attention over token-major qkv [B*T, 3H] (T dtype, q pre-scaled), out [B*T, H]; hd == 64.
 // log2_scores: q was scaled by log2(e)/sqrt(hd) instead of 1/sqrt(hd), so softmax uses exp2 directly.
 hipError_t launch_attention(DType dt, const void* qkv, void* out, int B, int T, int H, int nh, bool log2_scores,

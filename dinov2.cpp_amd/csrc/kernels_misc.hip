@@ -123,6 +123,92 @@ hipError_t launch_layernorm_f32(const float* x, const float* w, const float* b, 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// LN fold (kernels.h, EPI_RESID_LN): the two small kernels beside the GEMM epilogues.
+//  * ln_prepare_kernel: what EPI_RESID_LN leaves behind, for a residual stream no GEMM has written yet (the embeddings, before layer 0):
+//    xg = T(x gamma) and per row and 64-column group (sum, sum of squares) in the producers' fixed pairwise order (ln_leaf4, then 16 lanes
+//    by row-local DPP).  One wave per row.
+//  * ln_fold_vectors_kernel (load time): s[n] = sum_k gamma_k W[n, k], c[n] = bias[n] + sum_k beta_k W[n, k] from the CONVERTED weights
+//    (the values the MFMA will see), accumulated in double.  One wave per output column.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int MAXV>
+__global__ __launch_bounds__(256) void ln_prepare_kernel(const float* __restrict__ x, const float* __restrict__ gamma, T* __restrict__ xg,
+                                                         float* __restrict__ stats, int gs, int rows, int H) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = H >> 2;
+    const float4* xr = (const float4*)(x + (size_t)row * H);
+    typedef T o4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = lane + 64 * j;  // (H % 64 == 0: a 16-lane row is inside the matrix or outside it as a whole)
+        if (i < nv) {
+            const float4 v = xr[i], g = ((const float4*)gamma)[i];
+            float g0 = v.x * g.x, g1 = v.y * g.y, g2 = v.z * g.z, g3 = v.w * g.w;
+            asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));  // f32 products first, then the rounding
+            o4 pk;
+            pk[0] = (T)g0; pk[1] = (T)g1; pk[2] = (T)g2; pk[3] = (T)g3;
+            ((o4*)(xg + (size_t)row * H))[i] = pk;
+            float s4, q4;
+            ln_leaf4(v.x, v.y, v.z, v.w, s4, q4);
+            s4 += dpp_f32<0xB1>(s4);
+            q4 += dpp_f32<0xB1>(q4);
+            s4 += dpp_f32<0x4E>(s4);
+            q4 += dpp_f32<0x4E>(q4);
+            s4 += dpp_f32<0x141>(s4);
+            q4 += dpp_f32<0x141>(q4);
+            s4 += dpp_f32<0x140>(s4);
+            q4 += dpp_f32<0x140>(q4);
+            if ((lane & 15) == 0) *(float2*)(stats + ((size_t)row * gs + (i >> 4)) * 2) = make_float2(s4, q4);
+        }
+    }
+}
+
+hipError_t launch_ln_prepare(DType dt, const float* x, const float* gamma, void* xg, float* stats, int gs, int rows, int H, hipStream_t st) {
+    if (H % 64 != 0 || H > 64 * 4 * 8) return hipErrorInvalidValue;
+    const dim3 grid((rows + 3) / 4), block(256);
+    const int nv = (H / 4 + 63) / 64;
+#define DINO_LNP(TT, MV) hipLaunchKernelGGL((ln_prepare_kernel<TT, MV>), grid, block, 0, st, x, gamma, (TT*)xg, stats, gs, rows, H)
+    if (dt == DT_F16) {
+        if (nv <= 2) DINO_LNP(_Float16, 2); else if (nv <= 4) DINO_LNP(_Float16, 4); else DINO_LNP(_Float16, 8);
+    } else {
+        if (nv <= 2) DINO_LNP(__bf16, 2); else if (nv <= 4) DINO_LNP(__bf16, 4); else DINO_LNP(__bf16, 8);
+    }
+#undef DINO_LNP
+    return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ln_fold_vectors_kernel(const T* __restrict__ W, const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ s, float* __restrict__ c, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const T* w = W + (size_t)n * K;
+    double sg = 0.0, sb = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        const double wv = (double)(float)w[k];
+        sg += (double)gamma[k] * wv;
+        sb += (double)beta[k] * wv;
+    }
+    sg = wave_sum_f64(sg);
+    sb = wave_sum_f64(sb);
+    if (lane == 0) {
+        s[n] = (float)sg;
+        c[n] = (float)((bias ? (double)bias[n] : 0.0) + sb);
+    }
+}
+
+hipError_t launch_ln_fold_vectors(DType dt, const void* W, const float* bias, const float* gamma, const float* beta, float* s, float* c, int N, int K,
+                                  hipStream_t st) {
+    const dim3 grid((N + 3) / 4), block(256);
+    if (dt == DT_F16) hipLaunchKernelGGL((ln_fold_vectors_kernel<_Float16>), grid, block, 0, st, (const _Float16*)W, bias, gamma, beta, s, c, N, K);
+    else hipLaunchKernelGGL((ln_fold_vectors_kernel<__bf16>), grid, block, 0, st, (const __bf16*)W, bias, gamma, beta, s, c, N, K);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // im2col of ggml_conv_2d_sk_p0 (/root/reference/dinov2.cpp:636): image -> [B*P, Kpad] in the kernel's type,
 // patch vector order (c, ky, kx) with kx fastest == flattening the [H,3,14,14] weight row; c is the RGB index
 // (dino_predict repacks BGR-interleaved to RGB-planar first, dinov2.cpp:914-931 -- folded into the gather here).

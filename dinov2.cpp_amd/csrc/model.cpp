@@ -122,12 +122,18 @@ struct Plan {
         int N, K, Kpad;     // matrix dims (rows, cols, padded cols)
         int interleaveF;    // SwiGLU weights_in row interleave (0 = off)
         size_t offset, bytes;
+        bool derived;       // no GGUF tensor behind it: computed on the device after the upload (LN-fold vectors)
     };
     std::vector<Item> items;
     size_t total = 0;
     void add(const std::string& name, void** slot, bool matrix, int N, int K, int Kpad, int F, size_t bytes) {
-        Item it{name, slot, matrix, N, K, Kpad, F, total, bytes};
+        Item it{name, slot, matrix, N, K, Kpad, F, total, bytes, false};
         total += align_up(bytes, 256);
+        items.push_back(it);
+    }
+    void add_derived(const std::string& name, float** slot, int count) {
+        Item it{name, (void**)slot, false, count, 1, 1, 0, total, sizeof(float) * (size_t)count, true};
+        total += align_up(it.bytes, 256);
         items.push_back(it);
     }
 };
@@ -135,6 +141,9 @@ struct Plan {
 struct Dims {
     int P, T, M;
 };
+
+// dinov2_hip_load_opts.ln_fold == 0: what the library picks (profiles/r06_ln_fold.md)
+constexpr bool kLnFoldDefault = false;
 
 }  // namespace
 
@@ -176,6 +185,7 @@ extern "C" void dinov2_hip_default_load_opts(dinov2_hip_load_opts* o) {
     o->quirk_pool_const_divisor = 1;
     o->quirk_pool_includes_registers = 1;
     o->batch_invariant = 1;
+    o->ln_fold = 0;
 }
 
 extern "C" int dinov2_hip_abi_version(void) { return DINOV2_HIP_ABI_VERSION; }
@@ -236,6 +246,16 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
     m->device = opts.device;
     m->quirk_const_div = opts.quirk_pool_const_divisor != 0;
     m->quirk_pool_regs = opts.quirk_pool_includes_registers != 0;
+    {
+        // LN fold: on request (ln_fold = 1, or DINOV2_HIP_LN_FOLD=1 while the option says "library's choice"), where the model allows it.
+        // The library's own choice is in kLnFoldDefault.
+        int want = opts.ln_fold;
+        if (want == 0)
+            if (const char* e = getenv("DINOV2_HIP_LN_FOLD")) want = atoi(e) != 0 ? 1 : -1;
+        if (want == 0) want = kLnFoldDefault ? 1 : -1;
+        const int Hh = (int)hp.hidden_size;
+        m->ln_fold = want > 0 && Hh % 128 == 0 && Hh / LN_GROUP <= LN_MAX_GROUPS;
+    }
 
     const int H = (int)hp.hidden_size, L = (int)hp.num_hidden_layers, nh = (int)hp.num_attention_heads;
     const int ps = (int)hp.patch_size, R = (int)hp.num_register_tokens;
@@ -337,6 +357,13 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
             vec(b + "mlp.fc2.bias", &ly.fc2_b, H);
         }
         vec(b + "layer_scale2.lambda1", &ly.ls2, H);
+        if (m->ln_fold) {
+            const int nfc1 = swiglu ? 2 * F : F;
+            plan.add_derived(b + "ln_fold.qkv_s", &ly.qkv_s, 3 * H);
+            plan.add_derived(b + "ln_fold.qkv_c", &ly.qkv_c, 3 * H);
+            plan.add_derived(b + "ln_fold.fc1_s", &ly.fc1_s, nfc1);
+            plan.add_derived(b + "ln_fold.fc1_c", &ly.fc1_c, nfc1);
+        }
     }
     vec("layernorm.weight", &m->ln_w, H);
     vec("layernorm.bias", &m->ln_b, H);
@@ -348,6 +375,7 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
     // validate every tensor against the plan before touching the device
     size_t max_raw = 0;
     for (auto& it : plan.items) {
+        if (it.derived) continue;
         const GgufTensor* gt = nullptr;
         if (!need(it.name, &gt)) return DINOV2_HIP_ERR_FORMAT;
         const uint64_t want = it.matrix ? (uint64_t)it.N * it.K : (uint64_t)it.N;
@@ -402,6 +430,7 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
         HIP_TRY(hipMalloc((void**)&staging, align_up(max_raw, 256)));
         int rc = DINOV2_HIP_OK;
         for (auto& it : plan.items) {
+            if (it.derived) continue;
             const GgufTensor* gt = gg.tensor(it.name);
             hipError_t e = hipSuccess;
             if (!it.matrix && it.interleaveF == 0) {
@@ -425,6 +454,14 @@ extern "C" int dinov2_hip_model_load(const char* path, const dinov2_hip_load_opt
         }
         (void)hipFree(staging);
         if (rc != DINOV2_HIP_OK) return rc;
+        if (m->ln_fold) {  // s / c of the QKV and FFN-in weights under the LayerNorm in front of them, from the converted weights
+            for (int i = 0; i < L; ++i) {
+                const LayerWeights& ly = m->layers[(size_t)i];
+                HIP_TRY(launch_ln_fold_vectors(m->dt, ly.qkv_w, ly.qkv_b, ly.norm1_w, ly.norm1_b, ly.qkv_s, ly.qkv_c, 3 * H, H, nullptr));
+                HIP_TRY(launch_ln_fold_vectors(m->dt, ly.fc1_w, ly.fc1_b, ly.norm2_w, ly.norm2_b, ly.fc1_s, ly.fc1_c, swiglu ? 2 * F : F, H, nullptr));
+            }
+            HIP_TRY(hipDeviceSynchronize());
+        }
     }
     arena_guard.m = nullptr;  // success: the arena now belongs to the model (dinov2_hip_model_free)
     *out = m.release();
@@ -477,7 +514,7 @@ Dims dims_of(const dinov2_hip_model* m, int B, int h, int w) {
 }
 
 struct Carve {
-    size_t img, col, x, ln, qkv, att, hid, fin, feat, logits, probs, pos, total;
+    size_t img, col, x, ln, qkv, att, hid, fin, feat, logits, probs, pos, stats, stats_bytes, total;
 };
 
 Carve carve_of(const dinov2_hip_model* m, int B, int h, int w) {
@@ -506,6 +543,8 @@ Carve carve_of(const dinov2_hip_model* m, int B, int h, int w) {
     c.logits = put(sizeof(float) * (size_t)B * C);
     c.probs = put(sizeof(float) * (size_t)B * C);
     c.pos = put(sizeof(float) * (size_t)(1 + d.P) * H);
+    c.stats_bytes = m->ln_fold ? sizeof(float) * 2 * (size_t)d.M * ln_stat_slots((int)H) : 0;
+    c.stats = put(c.stats_bytes);
     c.total = off;
     return c;
 }
@@ -536,6 +575,9 @@ int ensure_workspace(dinov2_hip_session* s, int B, int h, int w, char* err, size
     s->logits = (float*)(s->ws + c.logits);
     s->probs = (float*)(s->ws + c.probs);
     s->pos = (float*)(s->ws + c.pos);
+    s->stats = s->model->ln_fold ? (float*)(s->ws + c.stats) : nullptr;
+    // (the slots past hidden / 64 of every statistics row are read by the consumers and written by nobody: zero them with the carve)
+    if (c.stats_bytes) HIP_TRY(hipMemsetAsync(s->stats, 0, c.stats_bytes, s->stream));
     s->pos_h = s->pos_w = -1;  // the carve moved: re-upload the pos-embed
     s->cur_b = B;
     s->cur_h = h;
@@ -634,30 +676,39 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
     {
         Scope sc(s, K_PATCH_GEMM);
         GemmArgs a{};
-        a.sched = s->sched;
         a.A = s->col; a.W = m->patch_w; a.bias = m->patch_b; a.out = s->x; a.aux = s->pos;
         a.M = B * d.P; a.N = H; a.K = m->kpe_pad; a.ldo = H; a.P = d.P; a.T = d.T; a.R = R;
         HIP_TRY(launch_gemm(dt, EPI_PATCH, a, st));
     }
     const float eps = m->hp.eps;
+    // LN fold (dinov2_hip_load_opts.ln_fold; kernels.h EPI_RESID_LN): no LayerNorm launches inside the layers.  `ln` holds T(gamma x) for the
+    // NEXT LayerNorm and `stats` the row sums behind it, both written by whoever wrote x last: ln_prepare before layer 0, the residual
+    // epilogues afterwards; the QKV / FFN-in epilogues apply mean, rstd and beta.
+    const bool fold = m->ln_fold;
+    const int gs = ln_stat_slots(H);
+    if (fold && nlayers > 0) {
+        Scope sc(s, K_LAYERNORM);
+        HIP_TRY(launch_ln_prepare(dt, s->x, m->layers[0].norm1_w, s->ln, s->stats, gs, d.M, H, st));
+    }
     for (int il = 0; il < nlayers; ++il) {
         const LayerWeights& ly = m->layers[(size_t)il];
-        {
+        if (!fold) {
             Scope sc(s, K_LAYERNORM);
             HIP_TRY(launch_layernorm(dt, s->x, ly.norm1_w, ly.norm1_b, s->ln, d.M, H, eps, st));
         }
         {
             Scope sc(s, K_QKV_GEMM);
             GemmArgs a{};
-            a.sched = s->sched;
-        a.sched = s->sched;
             a.A = s->ln; a.W = ly.qkv_w; a.bias = ly.qkv_b; a.out = s->qkv;
             a.M = d.M; a.N = 3 * H; a.K = H; a.ldo = 3 * H; a.qcols = H;
 #if defined(DINO_PREC) && (DINO_PREC & 25)
             a.ldo = 6 * H;
 #endif
             a.qscale = 0.125f * 1.44269504088896340736f;  // 1/sqrt(64) (dinov2.cpp:626) x log2(e): softmax runs on exp2
-            HIP_TRY(launch_gemm(dt, EPI_QKV, a, st));
+            if (fold) {
+                a.stats = s->stats; a.ln_gs = gs; a.ln_s = ly.qkv_s; a.ln_c = ly.qkv_c; a.ln_eps = eps;
+            }
+            HIP_TRY(launch_gemm(dt, fold ? EPI_QKV_LN : EPI_QKV, a, st));
         }
         {
             Scope sc(s, K_ATTENTION);
@@ -666,33 +717,37 @@ int forward(dinov2_hip_session* s, const float* img, int B, int h, int w, int la
         {
             Scope sc(s, K_OPROJ_GEMM);
             GemmArgs a{};
-            a.sched = s->sched;
-        a.sched = s->sched;
             a.A = s->att; a.W = ly.o_w; a.bias = ly.o_b; a.out = s->x; a.aux = ly.ls1;
             a.M = d.M; a.N = H; a.K = H; a.ldo = H;
-            HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
+            if (fold) {
+                a.ln_gamma = ly.norm2_w; a.xg = s->ln; a.stats = s->stats; a.ln_gs = gs;
+            }
+            HIP_TRY(launch_gemm(dt, fold ? EPI_RESID_LN : EPI_RESID, a, st));
         }
-        {
+        if (!fold) {
             Scope sc(s, K_LAYERNORM);
             HIP_TRY(launch_layernorm(dt, s->x, ly.norm2_w, ly.norm2_b, s->ln, d.M, H, eps, st));
         }
         {
             Scope sc(s, K_FC1_GEMM);
             GemmArgs a{};
-            a.sched = s->sched;
-        a.sched = s->sched;
             a.A = s->ln; a.W = ly.fc1_w; a.bias = ly.fc1_b; a.out = s->hid;
             a.M = d.M; a.N = m->hp.swiglu ? 2 * F : F; a.K = H; a.ldo = F;
-            HIP_TRY(launch_gemm(dt, m->hp.swiglu ? EPI_SWIGLU : EPI_GELU, a, st));
+            if (fold) {
+                a.stats = s->stats; a.ln_gs = gs; a.ln_s = ly.fc1_s; a.ln_c = ly.fc1_c; a.ln_eps = eps;
+            }
+            HIP_TRY(launch_gemm(dt, m->hp.swiglu ? (fold ? EPI_SWIGLU_LN : EPI_SWIGLU) : (fold ? EPI_GELU_LN : EPI_GELU), a, st));
         }
         {
             Scope sc(s, K_FC2_GEMM);
             GemmArgs a{};
-            a.sched = s->sched;
-        a.sched = s->sched;
             a.A = s->hid; a.W = ly.fc2_w; a.bias = ly.fc2_b; a.out = s->x; a.aux = ly.ls2;
             a.M = d.M; a.N = H; a.K = F; a.ldo = H;
-            HIP_TRY(launch_gemm(dt, EPI_RESID, a, st));
+            const bool feeds_ln1 = fold && il + 1 < nlayers;  // (the last layer's x goes to the final LayerNorm kernel)
+            if (feeds_ln1) {
+                a.ln_gamma = m->layers[(size_t)il + 1].norm1_w; a.xg = s->ln; a.stats = s->stats; a.ln_gs = gs;
+            }
+            HIP_TRY(launch_gemm(dt, feeds_ln1 ? EPI_RESID_LN : EPI_RESID, a, st));
         }
     }
     if (!finalize) return DINOV2_HIP_OK;
@@ -849,11 +904,6 @@ extern "C" int dinov2_hip_session_create(dinov2_hip_model* m, void* stream, dino
         HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         s->own_stream = true;
     }
-#ifdef DINO_WITH_GEMM5
-    // (opt-in build with tools/probes/gemm5.hip) this session's own tile-ticket counters: sessions run on their own streams and may overlap
-    HIP_TRY(hipMalloc((void**)&s->sched, GEMM_SCHED_BYTES));
-    HIP_TRY(hipMemset(s->sched, 0, GEMM_SCHED_BYTES));
-#endif
     *out = s.release();
     return DINOV2_HIP_OK;
 }
@@ -869,7 +919,6 @@ extern "C" void dinov2_hip_session_free(dinov2_hip_session* s) {
     if (s->ws) (void)hipFree(s->ws);
     if (s->raw) (void)hipFree(s->raw);
     if (s->pca_buf) (void)hipFree(s->pca_buf);
-    if (s->sched) (void)hipFree(s->sched);
     if (s->own_stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -1206,7 +1255,6 @@ extern "C" int dinov2_hip_pca3(dinov2_hip_session* s, const float* tokens, int32
     }
     HIP_TRY(launch_pca_prepare(tok, d_mean, buf + o_xt, P, H, Ppad, st));
     GemmArgs a{};  // P * C = Xt Xt^T: both operands are the same [H, Ppad] matrix
-    a.sched = s->sched;
     a.A = buf + o_xt; a.W = buf + o_xt; a.out = d_cov; a.M = H; a.N = H; a.K = Ppad; a.ldo = H;
     HIP_TRY(launch_gemm(DT_F16, EPI_PLAIN_F32, a, st));
 

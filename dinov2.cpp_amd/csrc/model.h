@@ -14,6 +14,9 @@ namespace dinov2 {
 struct LayerWeights {
     float *norm1_w, *norm1_b, *qkv_b, *o_b, *ls1, *norm2_w, *norm2_b, *fc1_b, *fc2_b, *ls2;
     void *qkv_w, *o_w, *fc1_w, *fc2_w;  // compute dtype, [N, K] row-major (ggml ne = [K, N])
+    // LN fold (kernels.h): s[n] = sum_k gamma_k W[n, k], c[n] = bias[n] + sum_k beta_k W[n, k] of the QKV / FFN-in weights with the
+    // LayerNorm in front of them; derived at load, part of the arena (so they travel with a weight broadcast)
+    float *qkv_s = nullptr, *qkv_c = nullptr, *fc1_s = nullptr, *fc1_c = nullptr;
 };
 
 }  // namespace dinov2
@@ -24,6 +27,7 @@ struct dinov2_hip_model {
     dinov2::DType dt = dinov2::DT_F16;
     int device = 0;
     bool quirk_const_div = true, quirk_pool_regs = true;
+    bool ln_fold = false;      // LayerNorm 1 / 2 of every layer folded into the neighbouring GEMM epilogues (dinov2_hip_load_opts.ln_fold)
     int kpe = 0, kpe_pad = 0;  // patch-embed K (3*p*p) and its padding to a multiple of 64
     char* arena = nullptr;     // ONE allocation, like model.buffer (dinov2.cpp:341)
     size_t arena_bytes = 0;
@@ -50,7 +54,6 @@ struct dinov2_hip_session {
     size_t ws_bytes = 0;
     uint8_t* raw = nullptr;  // raw 8-bit images for DINOV2_HIP_U8_BGR_HWC inputs
     size_t raw_bytes = 0;
-    unsigned* sched = nullptr;  // (opt-in build with tools/probes/gemm5.hip only) tile-ticket counters of the two-workgroups-per-CU GEMM; nullptr otherwise
     char* pca_buf = nullptr;  // dinov2_hip_pca3's device scratch, grown on demand
     size_t pca_bytes = 0;
     int last_b = 0, last_h = 0, last_w = 0;  // shape of the last un-split forward (0: none): what dinov2_hip_fetch copies out
@@ -61,6 +64,7 @@ struct dinov2_hip_session {
     float *img = nullptr, *x = nullptr, *fin = nullptr, *feat = nullptr, *logits = nullptr, *probs = nullptr,
           *pos = nullptr;
     void *col = nullptr, *ln = nullptr, *qkv = nullptr, *att = nullptr, *hid = nullptr;
+    float* stats = nullptr;  // LN fold: [M][ln_stat_slots(H)][2] row statistics of the residual stream (slots past H / 64 stay zero)
     int pos_h = -1, pos_w = -1;  // grid the cached interpolated pos-embed in `pos` belongs to
     std::vector<float> pos_stage;
     // hipGraph cache (the "allocr reuse" of the reference taken one step further): a forward that repeats with the same

@@ -100,6 +100,100 @@ extern "C" int dinov2_hip_op_gemm(int32_t dtype, int32_t epilogue, const float* 
     return 0;
 }
 
+// ---- LN fold (kernels.h): the producer epilogue, the consumer epilogues, the two small kernels, each alone ----
+extern "C" int dinov2_hip_op_gemm_resid_ln(int32_t dtype, const float* A, const float* W, const float* bias, const float* ls, const float* gamma,
+                                           float* x, float* xg, float* stats, int32_t M, int32_t N, int32_t K) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    if (gemm_init() != hipSuccess) return -1;
+    const int gs = ln_stat_slots(N);
+    DevBuf dA, dW, dV, dX, dG, dS;
+    OP_TRY(upload_as(dt, A, (size_t)M * K, dA));
+    OP_TRY(upload_as(dt, W, (size_t)N * K, dW));
+    OP_TRY(dV.alloc(sizeof(float) * 3 * (size_t)N));
+    float* v = (float*)dV.p;
+    OP_TRY(hipMemcpy(v, bias, sizeof(float) * N, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(v + N, ls, sizeof(float) * N, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(v + 2 * N, gamma, sizeof(float) * N, hipMemcpyHostToDevice));
+    OP_TRY(dX.alloc(sizeof(float) * (size_t)M * N));
+    OP_TRY(hipMemcpy(dX.p, x, sizeof(float) * (size_t)M * N, hipMemcpyHostToDevice));
+    OP_TRY(dG.alloc(2 * (size_t)M * N));
+    OP_TRY(hipMemset(dG.p, 0, 2 * (size_t)M * N));
+    OP_TRY(dS.alloc(sizeof(float) * 2 * (size_t)M * gs));
+    OP_TRY(hipMemset(dS.p, 0, sizeof(float) * 2 * (size_t)M * gs));
+    GemmArgs a{};
+    a.A = dA.p; a.W = dW.p; a.bias = v; a.aux = v + N; a.ln_gamma = v + 2 * N; a.out = dX.p; a.xg = dG.p; a.stats = (float*)dS.p; a.ln_gs = gs;
+    a.M = M; a.N = N; a.K = K; a.ldo = N;
+    OP_TRY(launch_gemm(dt, EPI_RESID_LN, a, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(hipMemcpy(x, dX.p, sizeof(float) * (size_t)M * N, hipMemcpyDeviceToHost));
+    OP_TRY(download_as(dt, dG.p, (size_t)M * N, xg));
+    OP_TRY(hipMemcpy(stats, dS.p, sizeof(float) * 2 * (size_t)M * gs, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_gemm_ln_consumer(int32_t dtype, int32_t epilogue, const float* A, const float* W, const float* ln_s, const float* ln_c,
+                                              const float* stats, float eps, float* out, int32_t ldo, int32_t M, int32_t N, int32_t K,
+                                              int32_t qcols, float qscale) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    if (gemm_init() != hipSuccess) return -1;
+    if (!epi_ln_consumer((Epilogue)epilogue)) return -1;
+    const int gs = ln_stat_slots(K);
+    DevBuf dA, dW, dV, dS, dO;
+    OP_TRY(upload_as(dt, A, (size_t)M * K, dA));
+    OP_TRY(upload_as(dt, W, (size_t)N * K, dW));
+    OP_TRY(dV.alloc(sizeof(float) * 2 * (size_t)N));
+    float* v = (float*)dV.p;
+    OP_TRY(hipMemcpy(v, ln_s, sizeof(float) * N, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(v + N, ln_c, sizeof(float) * N, hipMemcpyHostToDevice));
+    OP_TRY(dS.alloc(sizeof(float) * 2 * (size_t)M * gs));
+    OP_TRY(hipMemcpy(dS.p, stats, sizeof(float) * 2 * (size_t)M * gs, hipMemcpyHostToDevice));
+    const size_t on = (size_t)M * ldo;
+    OP_TRY(dO.alloc(on * 2));
+    OP_TRY(hipMemset(dO.p, 0, on * 2));
+    GemmArgs a{};
+    a.A = dA.p; a.W = dW.p; a.ln_s = v; a.ln_c = v + N; a.stats = (float*)dS.p; a.ln_gs = gs; a.ln_eps = eps; a.out = dO.p;
+    a.M = M; a.N = N; a.K = K; a.ldo = ldo; a.qcols = qcols; a.qscale = qscale;
+    OP_TRY(launch_gemm(dt, (Epilogue)epilogue, a, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(download_as(dt, dO.p, on, out));
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_ln_prepare(int32_t dtype, const float* x, const float* gamma, float* xg, float* stats, int32_t rows, int32_t H) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    const int gs = ln_stat_slots(H);
+    DevBuf dX, dV, dG, dS;
+    OP_TRY(dX.alloc(sizeof(float) * (size_t)rows * H));
+    OP_TRY(hipMemcpy(dX.p, x, sizeof(float) * (size_t)rows * H, hipMemcpyHostToDevice));
+    OP_TRY(dV.alloc(sizeof(float) * (size_t)H));
+    OP_TRY(hipMemcpy(dV.p, gamma, sizeof(float) * (size_t)H, hipMemcpyHostToDevice));
+    OP_TRY(dG.alloc(2 * (size_t)rows * H));
+    OP_TRY(dS.alloc(sizeof(float) * 2 * (size_t)rows * gs));
+    OP_TRY(hipMemset(dS.p, 0, sizeof(float) * 2 * (size_t)rows * gs));
+    OP_TRY(launch_ln_prepare(dt, (const float*)dX.p, (const float*)dV.p, dG.p, (float*)dS.p, gs, rows, H, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(download_as(dt, dG.p, (size_t)rows * H, xg));
+    OP_TRY(hipMemcpy(stats, dS.p, sizeof(float) * 2 * (size_t)rows * gs, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int dinov2_hip_op_ln_fold_vectors(int32_t dtype, const float* W, const float* bias, const float* gamma, const float* beta, float* s_out,
+                                             float* c_out, int32_t N, int32_t K) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    DevBuf dW, dV;
+    OP_TRY(upload_as(dt, W, (size_t)N * K, dW));
+    OP_TRY(dV.alloc(sizeof(float) * (3 * (size_t)N + 2 * (size_t)K)));
+    float* v = (float*)dV.p;
+    OP_TRY(hipMemcpy(v, bias, sizeof(float) * N, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(v + 3 * (size_t)N, gamma, sizeof(float) * K, hipMemcpyHostToDevice));
+    OP_TRY(hipMemcpy(v + 3 * (size_t)N + K, beta, sizeof(float) * K, hipMemcpyHostToDevice));
+    OP_TRY(launch_ln_fold_vectors(dt, dW.p, v, v + 3 * (size_t)N, v + 3 * (size_t)N + K, v + N, v + 2 * (size_t)N, N, K, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(hipMemcpy(s_out, v + N, sizeof(float) * N, hipMemcpyDeviceToHost));
+    OP_TRY(hipMemcpy(c_out, v + 2 * (size_t)N, sizeof(float) * N, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int dinov2_hip_op_attention(int32_t dtype, const float* qkv, float* out, int32_t B, int32_t T, int32_t H,
                                        int32_t nh) {
     const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
@@ -204,6 +298,21 @@ extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32
     a.lda = K + padA; a.ldw = K + padW;
     a.qcols = N / 3; a.qscale = 0.125f;
     if (epilogue == EPI_PATCH) { a.P = M; a.T = M + 1; }
+    DevBuf dSt, dXg, dV;
+    if (epilogue >= EPI_RESID_LN) {  // LN fold: statistics of unit-variance rows, gamma = 1, s = 0, c = 0
+        const int hc = epilogue == EPI_RESID_LN ? N : K;
+        const int gs = ln_stat_slots(hc), groups = hc / LN_GROUP;
+        std::vector<float> st((size_t)M * gs * 2, 0.f), ones((size_t)std::max(N, K), 1.0f);
+        for (int m = 0; m < M; ++m)
+            for (int g = 0; g < groups; ++g) st[((size_t)m * gs + g) * 2 + 1] = 64.0f;
+        if (dSt.alloc(st.size() * 4) != hipSuccess || dXg.alloc((size_t)M * N * 2) != hipSuccess || dV.alloc(ones.size() * 4) != hipSuccess) return -1.f;
+        (void)hipMemcpy(dSt.p, st.data(), st.size() * 4, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dV.p, ones.data(), ones.size() * 4, hipMemcpyHostToDevice);
+        a.stats = (float*)dSt.p; a.ln_gs = gs; a.ln_eps = 1e-6f;
+        a.ln_gamma = (const float*)dV.p; a.xg = dXg.p;
+        a.ln_s = (const float*)dB.p; a.ln_c = (const float*)dB.p;  // zeros
+        if (epilogue == EPI_SWIGLU_LN) a.ldo = N / 2;
+    }
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0);
     (void)hipEventCreate(&e1);
@@ -267,9 +376,9 @@ extern "C" int dinov2_hip_op_get_tuning(const char* key) {
 }
 // no device needed: nothing is launched and no pointer is dereferenced
 extern "C" int dinov2_hip_op_gemm_plan(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, char* out, int32_t cap) {
-    if (!out || cap <= 0 || epilogue < 0 || epilogue > 5) return DINOV2_HIP_ERR_INVALID;
+    if (!out || cap <= 0 || epilogue < 0 || epilogue > EPI_SWIGLU_LN) return DINOV2_HIP_ERR_INVALID;
     GemmArgs a{};
-    a.M = M; a.N = N; a.K = K; a.ldo = epilogue == EPI_SWIGLU ? N / 2 : N;
+    a.M = M; a.N = N; a.K = K; a.ldo = epi_base((Epilogue)epilogue) == EPI_SWIGLU ? N / 2 : N;
     a.P = 1; a.T = 2;
     a.qcols = N / 3;
     return gemm_plan_describe(dtype == 1 ? DT_BF16 : DT_F16, (Epilogue)epilogue, a, out, (size_t)cap) == hipSuccess ? DINOV2_HIP_OK : DINOV2_HIP_ERR_INVALID;

@@ -118,6 +118,10 @@ def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: i
     # once the outlier channels exist they dominate every row's variance: trained LayerNorm weights make up for it (large on the ordinary
     # channels, small on the outliers), so that the layers behind keep seeing O(1) inputs
     restore = np.float32(np.sqrt(1.0 + sum(b * b for b in TRAINED_OUTLIER_BIAS[: len(out_ch)]) / H))
+    # deeper than 24 layers the ordinary channels of a random-weight residual stream keep growing (and the scores with their square: 340 at
+    # layer 36 of the 40-layer ViT-g, where even the ggml-mode oracle is 21 logit units from exact arithmetic -- a chaotic system, not a
+    # test): smaller LayerScale keeps the deep models in the regime of the 24-layer one
+    ls_k = np.float32(min(1.0, (24.0 / L) ** 2))
 
     def norm_weight(name, after_outliers=False):
         g = normal((H,), 0.1) + np.float32(1.0)
@@ -161,7 +165,10 @@ def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: i
         w.add_tensor(b + "attention.attention.qkv.bias", qkv_bias)
         mat(b + "attention.output.dense.weight", (H, H), 0.02)
         vec(b + "attention.output.dense.bias", (H,), 0.05)
-        vec(b + "layer_scale1.lambda1", (H,), 0.1, 0.3)
+        ls1 = normal((H,), 0.1) + np.float32(0.3)
+        if trained_like:
+            ls1 *= ls_k
+        w.add_tensor(b + "layer_scale1.lambda1", ls1)
         norm_weight(b + "norm2.weight", i > l_out)
         vec(b + "norm2.bias", (H,), 0.05)
         fc1n, fc2n = ("mlp.weights_in", "mlp.weights_out") if cfg["swiglu"] else ("mlp.fc1", "mlp.fc2")
@@ -170,6 +177,8 @@ def write_synthetic_gguf(path: str, model: str | dict = "large", *, registers: i
         fc2 = normal((H, F), 0.02)
         fc2_bias = normal((H,), 0.05)
         ls2 = normal((H,), 0.1) + np.float32(0.3)
+        if trained_like:
+            ls2 *= ls_k
         if trained_like and i == l_out:  # the layer that writes the outlier channels into the residual stream
             fc2[out_ch] *= np.float32(TRAINED_OUTLIER_ROW_GAIN)
             fc2_bias[out_ch] = np.asarray(TRAINED_OUTLIER_BIAS[: len(out_ch)], np.float32)

@@ -63,7 +63,12 @@ typedef struct dinov2_hip_load_opts {
                                 of an over-long batch or the number of devices a dinov2_hip_group shards it over.  (Round 2 / early
                                 round 3 had an opt-in mode, 0, that split K at tiny batches; the small-tile plans that replaced it are
                                 faster than it was and keep the bits: profiles/r03_small_m_gemm.md.)                              */
-    int32_t reserved[9];
+    int32_t ln_fold; /* LayerNorm folded into the GEMMs on either side of it: 0 = the library's choice, 1 = on
+                        (where the model allows it: hidden % 128 == 0 and <= 1 536), -1 = off: separate LayerNorm launches that round
+                        f16(LN(x)) exactly where ggml does.  On: the residual epilogues emit f16(gamma x) + row statistics and the QKV /
+                        FFN-in epilogues apply mean, rstd and beta -- 2 of 7 launches per layer less; the activation is rounded BEFORE the
+                        normalisation instead of after it (same 2^-11 relative rounding per element; parity numbers: profiles/r06_*).      */
+    int32_t reserved[8];
 } dinov2_hip_load_opts;
 
 /* dino_hparams (dinov2.h:25-47) plus what the loader derives from the tensor list. */

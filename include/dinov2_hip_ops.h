@@ -16,11 +16,25 @@ extern "C" {
 #endif
 
 /* epilogue ids (csrc/kernels.h): 0 patch-embed(+bias+pos, token scatter) 1 qkv(+bias, q scaled) 2 residual
- * (x += ls*(acc+bias)) 3 gelu 4 swiglu 5 plain f32.  Replaces ggml_mul_mat call sites of dinov2.cpp:471,546,561,570,
+ * (x += ls*(acc+bias)) 3 gelu 4 swiglu 5 plain f32 (6 .. 9: the LN-fold variants, through dinov2_hip_op_gemm_resid_ln / _ln_consumer).  Replaces ggml_mul_mat call sites of dinov2.cpp:471,546,561,570,
  * 582,608,636 with their trailing elementwise nodes.  `out` is [out_rows, ldo] f32, read first for epilogues 0/2/5. */
 int dinov2_hip_op_gemm(int32_t dtype, int32_t epilogue, const float *A, const float *W, const float *bias,
                        const float *aux, int64_t aux_count, float *out, int32_t out_rows, int32_t ldo, int32_t M,
                        int32_t N, int32_t K, int32_t P, int32_t T, int32_t R, int32_t qcols, float qscale);
+
+/* LN fold (csrc/kernels.h, epilogues 6 .. 9), each piece alone.  Statistics rows hold `gs` = 12 (hidden <= 768) or 24
+ * slots of (sum, sum of squares) per 64 columns, the slots past hidden / 64 zero.
+ *   gemm_resid_ln: x [M, N] f32 in/out += ls * (A W^T + bias); xg [M, N] = T(x gamma) (returned as f32); stats [M][gs][2]
+ *   gemm_ln_consumer: epilogue 7 (qkv) | 8 (gelu) | 9 (swiglu) on v = r_m (acc - mean_m s[n]) + c[n], mean / r from `stats` [M][gs][2]
+ *   ln_prepare: xg and stats of a residual stream no GEMM has written;  ln_fold_vectors: s[n] = sum_k gamma_k W[n,k], c[n] = bias[n] + sum_k beta_k W[n,k] */
+int dinov2_hip_op_gemm_resid_ln(int32_t dtype, const float *A, const float *W, const float *bias, const float *ls, const float *gamma, float *x,
+                                float *xg, float *stats, int32_t M, int32_t N, int32_t K);
+int dinov2_hip_op_gemm_ln_consumer(int32_t dtype, int32_t epilogue, const float *A, const float *W, const float *ln_s, const float *ln_c,
+                                   const float *stats, float eps, float *out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t qcols,
+                                   float qscale);
+int dinov2_hip_op_ln_prepare(int32_t dtype, const float *x, const float *gamma, float *xg, float *stats, int32_t rows, int32_t H);
+int dinov2_hip_op_ln_fold_vectors(int32_t dtype, const float *W, const float *bias, const float *gamma, const float *beta, float *s_out,
+                                  float *c_out, int32_t N, int32_t K);
 
 /* fused attention over token-major qkv [B*T, 3H] (q already scaled) -> [B*T, H]; replaces dinov2.cpp:479-543 */
 int dinov2_hip_op_attention(int32_t dtype, const float *qkv, float *out, int32_t B, int32_t T, int32_t H, int32_t nh);
@@ -63,7 +77,7 @@ int dinov2_hip_op_set_tuning(const char *key, int32_t value);
 int dinov2_hip_op_get_tuning(const char *key); /* -1: unknown key */
 
 /* Which kernel plan launch_gemm picks for a shape, as text: ';'-separated leaves such as "gemm4_mixed<256+192>", "gemm2<128>",
- * "gemm4<256>;small<64x128,w2x2,st3,ks1>", "gemm5<192x128>".  Needs no device (nothing is launched).  0 on success. */
+ * "gemm4<256>;small<64x128,w2x2,st3,ks1>".  Needs no device (nothing is launched).  0 on success. */
 int dinov2_hip_op_gemm_plan(int32_t dtype, int32_t epilogue, int32_t M, int32_t N, int32_t K, char *out, int32_t cap);
 
 /* host-only: the Rayleigh-Ritz step behind dinov2_hip_pca3.  yprev [H][8] (any full-rank block), gram [8][8] = yprev^T yprev,

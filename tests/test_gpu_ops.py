@@ -475,15 +475,6 @@ def test_gemm_random_shapes_all_plans(api, seed):
 
 
 
-def _has_gen5(api):
-    """generation 5 (tools/probes/gemm5.hip) is an opt-in build: DINOV2_HIP_LIB=.../variants/libdinov2_hip_vg5.so (`make -C dinov2.cpp_amd g5`)"""
-    try:
-        api.set_tuning("gemm_gen", 5)
-        return "gemm5" in api.gemm_plan(F16, EPI_PLAIN, 43968, 1024, 1024)
-    finally:
-        api.set_tuning("gemm_gen", 0)
-
-
 def _gen_case(api, rng, dt, epi, M, N, K, gens, expect):
     """One shape through the listed generations of the persistent GEMM (`expect[gen]` = a kernel name the dispatcher's plan for that
     generation must contain, so that the comparison provably runs the kernels it claims to -- ADVICE r4); the rows repeat every 100, so
@@ -542,29 +533,12 @@ def test_gemm_generation_4_equals_generation_2_bit_for_bit(api, dt, epi):
             _gen_case(api, rng, dt, epi, 1374, N, 1024, (2, 4), {2: "gemm2<128>", 4: "gemm4_short<96>"})
 
 
-@pytest.mark.parametrize("dt", [F16, BF16])
-@pytest.mark.parametrize("epi", [EPI_QKV, EPI_RESID, EPI_GELU, EPI_SWIGLU, EPI_PLAIN])
-def test_gemm_generation_5_equals_generation_4_bit_for_bit(api, dt, epi):
-    """gemm5.hip (192 x 128 tiles, two independent workgroups per CU, tile hand-over through one barrier, epilogue slices inside K-tile
-    buffer 1) against gemm4.hip and the small-tile kernel: several tiles per workgroup with a ragged last panel (M % 192 != 0), K / 64 =
-    4, 6 and 16, N = 512 ... 2 048.  Generation 5 is a parked, opt-in build (profiles/r05_gemm5.md): skipped against the product library."""
-    if not _has_gen5(api):
-        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
-    rng = np.random.default_rng(50 + epi + dt)
-    _gen_case(api, rng, dt, epi, 40100, 512, 256, (4, 5), {4: "gemm4", 5: "gemm5<192x128>"})
-    _gen_case(api, rng, dt, epi, 23000, 1024, 384, (2, 5), {2: "gemm2", 5: "gemm5<192x128>"})
-    _gen_case(api, rng, dt, epi, 9300, 2048, 1024, (4, 5), {4: "gemm4", 5: "gemm5<192x128>"})
-
-
-@pytest.mark.parametrize("gen,M,N,K,name", [(4, 41100, 1024, 1024, "gemm4_mixed<256+192>"), (4, 98200, 512, 256, "gemm4<256>"),
-                                            (5, 23000, 1024, 512, "gemm5<192x128>")])
+@pytest.mark.parametrize("gen,M,N,K,name", [(4, 41100, 1024, 1024, "gemm4_mixed<256+192>"), (4, 98200, 512, 256, "gemm4<256>")])
 def test_gemm_generation_race_screen(api, gen, M, N, K, name):
     """Fifty repeats of a multi-round launch of the hand-ordered kernels (gemm4.hip: plan C, 256- and 192-row tiles, next tile staged under
-    the last K-tiles and the epilogue; plan A with four rounds; gemm5.hip: two workgroups per CU, tile hand-over) must reproduce the first
+    the last K-tiles and the epilogue; plan A with four rounds) must reproduce the first
     result bit for bit: a fragment read ahead of its LDS-DMA data, or a buffer re-staged under a reader, shows up as a rare differing
     tile.  The generation is forced and the plan asserted by name (the round-4 form of this test ran gemm2.hip)."""
-    if gen == 5 and not _has_gen5(api):
-        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
     rng = np.random.default_rng(77)
     A = _round(rng.standard_normal((M, K)), F16)
     W = _round(rng.standard_normal((N, K)) * 0.05, F16)
@@ -630,7 +604,7 @@ def _identity_operands(x, dt, N, ncols_x):
     return A, nparts
 
 
-_IMPLS = {"small": ("gemm_tile", 128, "small<"), "gemm2": ("gemm_gen", 2, "gemm2<"), "gemm4": ("gemm_gen", 4, "gemm4<"), "gemm5": ("gemm_gen", 5, "gemm5<")}
+_IMPLS = {"small": ("gemm_tile", 128, "small<"), "gemm2": ("gemm_gen", 2, "gemm2<"), "gemm4": ("gemm_gen", 4, "gemm4<")}
 
 
 @pytest.mark.parametrize("dt", [F16, BF16])
@@ -641,7 +615,7 @@ def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
     h for h >= 10 (ggml_gelu_f32; /root/reference/dinov2.cpp:567).  The epilogue evaluates the tanh form with v_exp_f32 / v_rcp_f32
     (1 ulp approximations), so an entry can differ from the exactly rounded table where the exact value lies within that error of an f16
     rounding boundary: the test COUNTS those entries, bounds them (<= 1 f16 ulp each) and records the counts in
-    gpurun_out/activation_sweeps_r05.json -- against the correctly rounded table AND against ggml's own f32-built table (the oracle's).  All four epilogue implementations (small-tile kernel, gemm2 / gemm4 / gemm5.hip) are
+    gpurun_out/activation_sweeps_r05.json -- against the correctly rounded table AND against ggml's own f32-built table (the oracle's).  All three epilogue implementations (small-tile kernel, gemm2 / gemm4.hip) are
     swept, each forced and asserted by plan name."""
     x = _all_finite_f16()
     N = 256
@@ -650,8 +624,6 @@ def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
     W[:, :nparts] = 1.0
     out = np.zeros((x.size, N), np.float32)
     key, val, name = _IMPLS[impl]
-    if impl == "gemm5" and not _has_gen5(api):
-        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
     try:
         api.set_tuning(key, val)
         plan = api.gemm_plan(dt, EPI_GELU, x.size, N, 256)
@@ -704,8 +676,6 @@ def test_swiglu_epilogue_exhaustive_silu(api, dt, impl):
     bias[is_x2] = 1.0
     out = np.zeros((x.size, F), np.float32)
     key, val, name = _IMPLS[impl]
-    if impl == "gemm5" and not _has_gen5(api):
-        pytest.skip("library built without generation 5 (make -C dinov2.cpp_amd g5)")
     try:
         api.set_tuning(key, val)
         plan = api.gemm_plan(dt, EPI_SWIGLU, x.size, 2 * F, 256)

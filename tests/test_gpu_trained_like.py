@@ -83,12 +83,15 @@ def test_trained_like_regime_is_reached(pkg, trained):
     assert 8.0 <= big <= 30.0
 
 
-def test_trained_like_vit_l_full_depth(api, pkg, trained):
+@pytest.mark.parametrize("fold", [-1, 1])
+def test_trained_like_vit_l_full_depth(api, pkg, trained, fold):
     """ViT-L/14 + 4 registers, all 24 layers, f16, 518 x 518, batch 2 (image 1 checked): HIP vs the oracle in its ggml-default mode and
-    in every ggml-uncertain switch mode, and vs exact arithmetic next to the oracle's own distance to it."""
+    in every ggml-uncertain switch mode, and vs exact arithmetic next to the oracle's own distance to it.  With separate LayerNorm launches
+    (fold = -1: f16(LN(x)) rounded exactly where ggml rounds it) and with the LayerNorm folded into the neighbouring GEMM epilogues (fold = 1:
+    the activation is rounded BEFORE the normalisation -- the outlier channels of this checkpoint are what that could hurt)."""
     path = trained("large")
     imgs = pkg.synth.synthetic_images(2, 518, 518, seed=42)
-    got = api.Session(api.Model(path, classify=True)).predict(imgs, classify=True, topk=5)
+    got = api.Session(api.Model(path, classify=True, ln_fold=fold)).predict(imgs, classify=True, topk=5)
     lg, tk = got["logits"][1], got["patch_tokens"][1]
     assert np.isfinite(lg).all() and np.isfinite(tk).all()
     ex = OracleModel(path).forward_exact(imgs[1], classify=True)
@@ -115,7 +118,7 @@ def test_trained_like_vit_l_full_depth(api, pkg, trained):
     rec["hip_over_worst_ggml_style"] = rec["hip_vs_exact_abs"] / worst
     rec["hip_tokens_over_worst_ggml_style"] = rec["hip_vs_exact_tokens_abs"] / worst_t
     rec["within_bound_absolute_1e-3"] = bool(rec["hip_vs_ggml_default_abs"] <= 1e-3)
-    _record("trained_like_vit_l_f16", **rec)
+    _record("trained_like_vit_l_f16" + ("_ln_fold" if fold > 0 else ""), **rec)
     # the stated contract (relative to the largest logit / token value), against every switch mode and against exact arithmetic
     for name in _SWITCHES:
         assert rec[f"hip_vs_{name}_rel"] <= 1e-3, (name, rec)
@@ -130,13 +133,14 @@ def test_trained_like_vit_l_full_depth(api, pkg, trained):
     assert list(got["topk_ids"][1]) == top_ref
 
 
-def test_trained_like_hidden_states_per_layer(api, pkg, trained):
+@pytest.mark.parametrize("fold", [-1, 1])
+def test_trained_like_hidden_states_per_layer(api, pkg, trained, fold):
     """Where along the depth does the HIP path leave the oracle?  Residual stream after layers 1, 6, 12, 18, 24 of the trained-like ViT-L
     (dinov2_hip_debug_hidden vs the oracle's hidden states), relative to the largest entry of the ORDINARY channels (the outlier channels
     are 100 x larger and compared separately, relative to themselves)."""
     path = trained("large")
     img = pkg.synth.synthetic_images(1, 518, 518, seed=7)
-    sess = api.Session(api.Model(path, classify=True))
+    sess = api.Session(api.Model(path, classify=True, ln_fold=fold))
     hid = OracleModel(path).forward(img[0], classify=False, hidden=True)["hidden"]
     out_ch = pkg.synth.trained_outlier_channels(1024)
     ordinary = np.setdiff1d(np.arange(1024), out_ch)
@@ -146,12 +150,13 @@ def test_trained_like_hidden_states_per_layer(api, pkg, trained):
         d = np.abs(h - hid[layer])
         rec[f"layer{layer}_ordinary_rel"] = float(d[:, ordinary].max() / np.abs(hid[layer][:, ordinary]).max())
         rec[f"layer{layer}_outlier_rel"] = float(d[:, out_ch].max() / np.abs(hid[layer][:, out_ch]).max())
-    _record("trained_like_vit_l_hidden", **rec)
+    _record("trained_like_vit_l_hidden" + ("_ln_fold" if fold > 0 else ""), **rec)
     for k, v in rec.items():
         assert v <= 5e-3, (k, rec)
 
 
-def test_trained_like_vit_g_bf16_full_depth(api, pkg, trained):
+@pytest.mark.parametrize("fold", [-1, 1])
+def test_trained_like_vit_g_bf16_full_depth(api, pkg, trained, fold):
     """ViT-g/14 SwiGLU, 40 layers, bf16 compute (BASELINE configs[3]'s dtype) on the trained-like statistics, batch 2; the same model in f16
     next to it.  Bounds: the full-depth ViT-g ones of tests/test_gpu_configs.py (bf16 2e-2 / 4e-2, f16 2e-3 / 5e-3)."""
     path = trained("giant")
@@ -161,12 +166,12 @@ def test_trained_like_vit_g_bf16_full_depth(api, pkg, trained):
     ex = ora.forward_exact(imgs[1], classify=True)
     rec = {"max_abs_logit": float(np.abs(exp["logits"]).max()), "ggml_default_vs_exact_abs": _abs(exp["logits"], ex["logits"])}
     for name, dt, lb, tb in (("bf16", api.BF16, 2e-2, 4e-2), ("f16", api.F16, 2e-3, 5e-3)):
-        got = api.Session(api.Model(path, dtype=dt, classify=True)).predict(imgs, classify=True, want=("logits", "probs", "patch_tokens"))
+        got = api.Session(api.Model(path, dtype=dt, classify=True, ln_fold=fold)).predict(imgs, classify=True, want=("logits", "probs", "patch_tokens"))
         rec[f"{name}_abs_dlogit"] = _abs(got["logits"][1], exp["logits"])
         rec[f"{name}_rel_dlogit"] = _rel(got["logits"][1], exp["logits"])
         rec[f"{name}_rel_dtoken"] = _rel(got["patch_tokens"][1], exp["patch_tokens"])
         rec[f"{name}_vs_exact_abs"] = _abs(got["logits"][1], ex["logits"])
         assert np.isfinite(got["logits"]).all()
-        _record("trained_like_vit_g", **rec)
+        _record("trained_like_vit_g" + ("_ln_fold" if fold > 0 else ""), **rec)
         assert rec[f"{name}_rel_dlogit"] <= lb, rec
         assert rec[f"{name}_rel_dtoken"] <= tb, rec

@@ -88,3 +88,45 @@ def test_gemm4_kernels_use_the_whole_register_file_and_little_scratch(gemm4_asm)
             assert 440 <= nvgpr <= 512, (name, nvgpr)
         n += 1
     assert n >= 20
+
+
+def _regs(tok):
+    """VGPR numbers named by an operand token: v12 -> {12}, v[24:27] -> {24, 25, 26, 27}; anything else -> {}."""
+    m = re.fullmatch(r"v(\d+)", tok)
+    if m:
+        return {int(m.group(1))}
+    m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    return set()
+
+
+def test_gemm4_no_instruction_touches_a_fragment_before_its_wait(gemm4_asm):
+    """The fragment reads are `asm volatile("ds_read_b128 ...")` statements whose s_waitcnt is ANOTHER statement: to the compiler the output
+    register holds its value the moment the statement ends.  Anything it places in between that reads or moves such a register -- a spill,
+    an AGPR park, a copy -- picks up whatever the register held BEFORE the LDS data arrived.  Round 6 hit exactly that: under the register
+    pressure of the first EPI_QKV_LN epilogue hipcc spilled Pw[3] right behind its ds_read (scratch_store two lines later, the wait after it);
+    every tile lost its first k-step in sixteen columns.  Checked here for every gemm4 kernel, over the whole function: between a
+    ds_read_b128 and the next `s_waitcnt lgkmcnt(0)` no other instruction may name the destination registers."""
+    checked = 0
+    for name, body in _functions(gemm4_asm):
+        pending = set()
+        for line in body.splitlines():
+            s = line.split(";")[0].strip()
+            if not s or s.startswith(".") or s.endswith(":"):
+                continue
+            op, _, rest = s.partition(" ")
+            toks = [t.strip() for t in rest.split(",")] if rest else []
+            if op == "s_waitcnt" and "lgkmcnt(0)" in rest:
+                pending.clear()
+                continue
+            if op == "ds_read_b128":
+                pending |= _regs(toks[0])
+                checked += 1
+                continue
+            if pending:
+                used = set()
+                for t in toks:
+                    used |= _regs(t.split(" ")[0])
+                assert not (used & pending), (name, s, sorted(used & pending))
+    assert checked > 1000
