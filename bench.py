@@ -545,7 +545,7 @@ def main():
                 "sustained_mfma_tflops_random_operands": 1750.0, "frac_of_sustained": round(ach / 1750.0, 4)}
 
     # ---- p50 latency at batch 1 (the other half of BASELINE.json's metric) ----
-    p50 = p99 = p50_224 = p99_224 = None
+    p50 = p99 = p50_224 = p99_224 = p50_fold = p50_224_fold = None
     if not args.no_latency:
         one = imgs[:1].contiguous()
 
@@ -568,6 +568,17 @@ def main():
         s224 = api.Session(model)
         p50_224, p99_224 = latency(s224, torch.randn((1, 3, 224, 224), generator=gen, device=f"cuda:{local}", dtype=torch.float32), 224)
         del s224
+        # the library's latency option (dinov2_hip_load_opts.ln_fold = 1: LayerNorm 1 / 2 carried by the neighbouring GEMM epilogues, five
+        # launches per layer instead of seven; opt-in because it costs 2.5 % of the batch-32 rate -- profiles/r06_ln_fold.md).  Rank 0, N = 1 only.
+        if world == 1 and os.environ.get("DINOV2_HIP_LN_FOLD") is None:
+            try:
+                mf = api.Model(path, device=local, dtype=dt, classify=True, ln_fold=1)
+                sf = api.Session(mf)
+                p50_fold, _ = latency(sf, one, S)
+                p50_224_fold, _ = latency(sf, torch.randn((1, 3, 224, 224), generator=gen, device=f"cuda:{local}", dtype=torch.float32), 224)
+                del sf, mf
+            except api.DinoError:
+                pass
 
     # ---- side measurement, NOT the headline: the same batch split over two sessions (two HIP streams) on this GPU.  The other
     #      stream's kernels fill the idle CUs of a GEMM's last round; per-kernel durations of overlapped launches would mean
@@ -694,6 +705,8 @@ def main():
         "p50_latency_ms_batch1": p50, "p99_latency_ms_batch1": p99,
         "latency_mode": "batch-invariant kernels (batch-1 bits == the image's bits inside any batch)",
         "p50_latency_ms_batch1_224x224": p50_224, "p99_latency_ms_batch1_224x224": p99_224,
+        "p50_latency_ms_batch1_ln_fold": p50_fold, "p50_latency_ms_batch1_224x224_ln_fold": p50_224_fold,
+        "ln_fold": os.environ.get("DINOV2_HIP_LN_FOLD", "0") not in ("0", ""),  # (the headline runs the library's default: off)
         "two_sessions_images_per_sec": two_stream,
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),

@@ -70,6 +70,13 @@ static __device__ __forceinline__ void static_for(F&& f) {
 #ifndef DINO_GEMM4_NT
 #define DINO_GEMM4_NT 0
 #endif
+// -DDINO_LN_ABL=<bits> (TIMING-ONLY tuning builds, results are wrong): which parts of the LN-fold epilogues are left out, to price them
+// (profiles/r06_ln_fold.md).  Consumers: 1 no next-tile statistics prefetch, 2 no s / c lane exchange, 4 no row-coefficient lane exchange,
+// 8 plain add instead of the two fused multiply-adds.  Producer: 16 no row statistics (DPP reduction + store), 32 no xg conversion / store,
+// 64 three passes of residual rows in flight instead of two.
+#ifndef DINO_LN_ABL
+#define DINO_LN_ABL 0
+#endif
 
 // Clock probe slots of this file's kernels (device_types.h, "clock probe")
 __device__ unsigned long long g_clk4[CLK_SLOTS * 4];
@@ -443,6 +450,11 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int f = cg * 16 + b * 8 + j * 4 + eq;  // this lane's float4 of block (b, j), as an index into the wave's 128 columns
+                        if constexpr (DINO_LN_ABL & 2) {
+                            lsv[b][j] = lnsc;
+                            lcv[b][j] = lnsc;
+                            continue;
+                        }
                         lsv[b][j] = make_float4(__shfl(lnsc.x, f), __shfl(lnsc.y, f), __shfl(lnsc.z, f), __shfl(lnsc.w, f));
                         lcv[b][j] = make_float4(__shfl(lnsc.x, 32 + f), __shfl(lnsc.y, 32 + f), __shfl(lnsc.z, 32 + f), __shfl(lnsc.w, 32 + f));
                     }
@@ -451,7 +463,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
             // column group is done (st_r / st_n of the current tile were handed out above)
             LnRaw lraw;
             LnAcc lacc;
-            const bool ln_next = LNC && cg < LNH && has_next;
+            const bool ln_next = LNC && cg < LNH && has_next && !(DINO_LN_ABL & 1);
             if constexpr (LNC) {
                 if (ln_next) ln_row_load<0>(p.stats, ln_row_of(nm0, cg), ln_gs, lraw);
             }
@@ -473,6 +485,11 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                     if constexpr (LNC) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
+                            if constexpr (DINO_LN_ABL & 4) {
+                                lnr[i] = cu_r[q < LNH ? q : 0];
+                                lnn[i] = cu_n[q < LNH ? q : 0];
+                                continue;
+                            }
                             lnr[i] = __shfl(cu_r[q < LNH ? q : 0], 16 * i + er);
                             lnn[i] = __shfl(cu_n[q < LNH ? q : 0], 16 * i + er);
                         }
@@ -507,7 +524,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
 #pragma unroll
                                     for (int e2 = 0; e2 < 2; ++e2) {
                                         f32x2 v = {DINO4_ACC(q, b, i, j)[2 * e2], DINO4_ACC(q, b, i, j)[2 * e2 + 1]};
-                                        if constexpr (LNC) {  // r (acc - mean s[n]) + c[n] as two fused multiply-adds per column (v_pk_fma_f32)
+                                        if constexpr (LNC && !(DINO_LN_ABL & 8)) {  // r (acc - mean s[n]) + c[n] as two fused multiply-adds per column (v_pk_fma_f32)
                                             const f32x2 d = __builtin_elementwise_fma(f32x2{lnn[LNC ? ir : 0], lnn[LNC ? ir : 0]}, f32x2{sb[2 * e2], sb[2 * e2 + 1]},
                                                                                       f32x2{bb[2 * e2], bb[2 * e2 + 1]});
                                             v = __builtin_elementwise_fma(f32x2{lnr[LNC ? ir : 0], lnr[LNC ? ir : 0]}, v, d);
@@ -529,7 +546,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
 #pragma unroll
                                     for (int e = 0; e < 4; ++e) {
                                         float v;
-                                        if constexpr (LNC) v = __builtin_fmaf(lnr[LNC ? ir : 0], DINO4_ACC(q, b, i, j)[e], __builtin_fmaf(lnn[LNC ? ir : 0], sb[e], bb[e]));
+                                        if constexpr (LNC && !(DINO_LN_ABL & 8)) v = __builtin_fmaf(lnr[LNC ? ir : 0], DINO4_ACC(q, b, i, j)[e], __builtin_fmaf(lnn[LNC ? ir : 0], sb[e], bb[e]));
                                         else v = DINO4_ACC(q, b, i, j)[e] + bb[e];
                                         asm("" : "+v"(v));  // a real f32 sum: no "add, then round" fusion into v_fma_mixlo_f16
                                         if constexpr (EB == EPI_QKV) {
@@ -656,7 +673,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
             // statistics group of its rows: 16 lanes per row, reduced with row-local DPP in the fixed pairwise order of ln_leaf4 (4 -> 8 ->
             // 16 -> 32 -> 64 columns; the small-tile kernel produces the same bits), and xg leaves as whole 128-byte lines.  LDS slice image:
             // 32 rows x 256 B, 16-byte slot s of row r at s ^ (r & 15).  Residual rows are requested PF passes ahead, as above.
-            constexpr int PF = 2;
+            constexpr int PF = (DINO_LN_ABL & 64) ? 3 : 2;
             float4 add[8][8];
             auto pass_of = [&](int ps8, int& cg, int& q, int& ih) {
                 cg = ps8 >> 2;
@@ -729,7 +746,7 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                     const bool live = m < M && (NI == 8 || rl < 16 * NI);
                     if (live) *(float4*)((float*)p.out + (size_t)m * p.ldo + nb) = v;
                     vec4 og;
-                    {
+                    if constexpr (!(DINO_LN_ABL & 32)) {
                         float g0 = v.x * gam.x, g1 = v.y * gam.y, g2 = v.z * gam.z, g3 = v.w * gam.w;
                         asm("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(g3));  // f32 products first, then the rounding
                         og[0] = E::from_f32(g0);
@@ -737,7 +754,10 @@ static __device__ __forceinline__ void gemm4_body(const GemmArgs& p, char* smem)
                         og[2] = E::from_f32(g2);
                         og[3] = E::from_f32(g3);
                     }
-                    if (live) *(vec4*)((T*)p.xg + (size_t)m * p.ldo + nb) = og;
+                    if constexpr (!(DINO_LN_ABL & 32)) {
+                        if (live) *(vec4*)((T*)p.xg + (size_t)m * p.ldo + nb) = og;
+                    }
+                    if constexpr (DINO_LN_ABL & 16) continue;
                     float s4, q4;
                     ln_leaf4(v.x, v.y, v.z, v.w, s4, q4);
                     s4 += dpp_f32<0xB1>(s4);   // 8 columns  (quad_perm [1,0,3,2])

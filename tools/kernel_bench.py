@@ -26,9 +26,11 @@ args = ap.parse_args()
 L = api.lib()
 H, F, T, B = args.hidden, args.ffn, args.tokens, args.batch
 M = B * T
-EPI = {"patch": 0, "qkv": 1, "resid": 2, "gelu": 3, "swiglu": 4, "plain": 5}
+EPI = {"patch": 0, "qkv": 1, "resid": 2, "gelu": 3, "swiglu": 4, "plain": 5, "resid_ln": 6, "qkv_ln": 7, "gelu_ln": 8, "swiglu_ln": 9}
 rows = [("qkv", "qkv", M, 3 * H, H), ("attn_out", "resid", M, H, H), ("ffn_in", "gelu", M, F, H),
-        ("ffn_out", "resid", M, H, F), ("plain_ffn_in", "plain", M, F, H)]
+        ("ffn_out", "resid", M, H, F), ("plain_ffn_in", "plain", M, F, H),
+        # the LN-fold variants of the same launches (csrc/kernels.h, epilogues 6 .. 9)
+        ("qkv_ln", "qkv_ln", M, 3 * H, H), ("attn_out_ln", "resid_ln", M, H, H), ("ffn_in_ln", "gelu_ln", M, F, H), ("ffn_out_ln", "resid_ln", M, H, F)]
 if args.shape:
     rows = [(a, b, int(c), int(d), int(e)) for a, b, c, d, e in (x.split(",") for x in args.shape)]
     args.only = ""
