@@ -3,10 +3,12 @@
 // stdout lines ("main: graph computation took N ms" is what scripts/benchmark.sh:73-77 scrapes), same flow: read the image ->
 // dino_model_load -> preprocess -> timed dino_predict -> top-k lines, or a 3-component PCA of the patch tokens -> min-max to
 // 0..255 -> patch grid -> nearest-neighbour resize to the preprocessed size -> image file.
-// Images are binary PPM (P6): the reference's decoders live in OpenCV, which this build does not link.
+// Images: JPEG (baseline and progressive, decoded to the bytes libjpeg / cv::imread produce -- examples/jpeg_codec.hpp) or binary PPM in;
+// JPEG (.jpg) or PPM out.  Defaults as the reference's: -i ../assets/tench.jpg, -o pca_visual.jpg (dinov2.h:65-66), so that
+// scripts/benchmark.sh:66-77 (`./bin/inference -c -m ../ggml-model.gguf -i ../assets/tench.jpg -t N`, scraping the line above) runs as is.
 //
-//   g++ -O2 -std=c++17 -I include examples/inference.cpp -o inference dinov2.cpp_amd/libdinov2_hip.so -Wl,-rpath,$PWD/dinov2.cpp_amd
-//   ./inference -m model.gguf -i image.ppm [-c] [-k 5] [-o pca_visual.ppm]
+//   make -C dinov2.cpp_amd examples        ->  build/bin/inference, build/bin/quantize, build/bin/realtime
+//   ./build/bin/inference -m model.gguf -i image.jpg [-c] [-k 5] [-o pca_visual.jpg]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,59 +18,15 @@
 #include <vector>
 
 #include "dinov2_compat.hpp"
-
-namespace {
-
-// binary PPM (P6, maxval 255) -> BGR interleaved like cv::imread
-bool read_ppm_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& h, int& w) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    auto token = [&](std::string& t) {
-        t.clear();
-        int c;
-        while ((c = fgetc(f)) != EOF) {
-            if (c == '#') { while ((c = fgetc(f)) != EOF && c != '\n') {} continue; }
-            if (!isspace(c)) { t.push_back((char)c); break; }
-        }
-        while ((c = fgetc(f)) != EOF && !isspace(c)) t.push_back((char)c);
-        return !t.empty();
-    };
-    std::string t;
-    bool ok = token(t) && t == "P6" && token(t);
-    if (ok) { w = atoi(t.c_str()); ok = token(t); }
-    if (ok) { h = atoi(t.c_str()); ok = token(t) && atoi(t.c_str()) == 255 && w > 0 && h > 0; }
-    if (ok) {
-        std::vector<uint8_t> rgb((size_t)h * w * 3);
-        ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
-        bgr.resize(rgb.size());
-        for (size_t i = 0; ok && i < rgb.size(); i += 3) { bgr[i] = rgb[i + 2]; bgr[i + 1] = rgb[i + 1]; bgr[i + 2] = rgb[i]; }
-    }
-    fclose(f);
-    return ok;
-}
-
-bool write_ppm_from_bgr(const std::string& path, const std::vector<uint8_t>& bgr, int h, int w) {
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) return false;
-    fprintf(f, "P6\n%d %d\n255\n", w, h);
-    std::vector<uint8_t> rgb(bgr.size());
-    for (size_t i = 0; i < bgr.size(); i += 3) { rgb[i] = bgr[i + 2]; rgb[i + 1] = bgr[i + 1]; rgb[i + 2] = bgr[i]; }
-    const bool ok = fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
-    fclose(f);
-    return ok;
-}
-
-}  // namespace
+#include "jpeg_codec.hpp"
 
 int main(int argc, char** argv) {
     dino_params params;
-    params.fname_inp = "../assets/tench.ppm";
-    params.image_out = "pca_visual.ppm";
     if (!dino_params_parse(argc, argv, params)) return 1;
     fprintf(stderr, "%s: seed = %u\n", __func__, params.seed);
     std::vector<uint8_t> bgr;
     int h = 0, w = 0;
-    if (!read_ppm_bgr(params.fname_inp, bgr, h, w)) {
+    if (!dinojpeg::imread_bgr(params.fname_inp, bgr, h, w)) {  // cv::imread(IMREAD_COLOR): JPEG (baseline / progressive) or binary PPM
         fprintf(stderr, "%s: failed to load image from '%s'\n", __func__, params.fname_inp.c_str());
         return 1;
     }
@@ -120,7 +78,7 @@ int main(int argc, char** argv) {
                 memcpy(&big[((size_t)y * ow + x) * 3], &small[((size_t)sy * gc + sx) * 3], 3);
             }
         }
-        if (write_ppm_from_bgr(params.image_out, big, oh, ow)) fprintf(stderr, "%s: Saved image to: %s\n", __func__, params.image_out.c_str());
+        if (dinojpeg::imwrite_bgr(params.image_out, big.data(), oh, ow)) fprintf(stderr, "%s: Saved image to: %s\n", __func__, params.image_out.c_str());
         else fprintf(stderr, "%s: failed to save image to '%s'\n", __func__, params.image_out.c_str());
     }
     return 0;

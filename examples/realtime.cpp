@@ -20,39 +20,12 @@
 #include <vector>
 
 #include "dinov2_compat.hpp"
+#include "jpeg_codec.hpp"
 
 constexpr int FRAME_WIDTH = 854;  // realtime.h:4-5
 constexpr int FRAME_HEIGHT = 480;
 
 namespace {
-
-bool read_ppm_bgr(const std::string& path, std::vector<uint8_t>& bgr, int& h, int& w) {
-    FILE* f = fopen(path.c_str(), "rb");
-    if (!f) return false;
-    char magic[3] = {0};
-    int maxv = 0;
-    bool ok = fscanf(f, "%2s %d %d %d", magic, &w, &h, &maxv) == 4 && !strcmp(magic, "P6") && maxv == 255 && w > 0 && h > 0;
-    if (ok) {
-        fgetc(f);  // the single whitespace after maxval
-        std::vector<uint8_t> rgb((size_t)h * w * 3);
-        ok = fread(rgb.data(), 1, rgb.size(), f) == rgb.size();
-        bgr.resize(rgb.size());
-        for (size_t i = 0; ok && i < rgb.size(); i += 3) { bgr[i] = rgb[i + 2]; bgr[i + 1] = rgb[i + 1]; bgr[i + 2] = rgb[i]; }
-    }
-    fclose(f);
-    return ok;
-}
-
-bool write_ppm_from_bgr(const std::string& path, const std::vector<uint8_t>& bgr, int h, int w) {
-    FILE* f = fopen(path.c_str(), "wb");
-    if (!f) return false;
-    fprintf(f, "P6\n%d %d\n255\n", w, h);
-    std::vector<uint8_t> rgb(bgr.size());
-    for (size_t i = 0; i < bgr.size(); i += 3) { rgb[i] = bgr[i + 2]; rgb[i + 1] = bgr[i + 1]; rgb[i + 2] = bgr[i]; }
-    const bool ok = fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
-    fclose(f);
-    return ok;
-}
 
 // cv::resize(src, dst, size, 0, 0, INTER_NEAREST) for 3-channel 8-bit images: source index = min(floor(dst * (1 / (dst/src))), src - 1)
 void resize_nearest(const uint8_t* src, int sh, int sw, uint8_t* dst, int dh, int dw) {
@@ -108,7 +81,7 @@ int main(int argc, char** argv) {
 
     std::vector<uint8_t> file_frame, frame, small((size_t)P * 3), pca_image((size_t)FRAME_HEIGHT * FRAME_WIDTH * 3), combined;
     int fh = 0, fw = 0;
-    if (!params.fname_inp.empty() && !read_ppm_bgr(params.fname_inp, file_frame, fh, fw)) {
+    if (!params.fname_inp.empty() && !dinojpeg::imread_bgr(params.fname_inp, file_frame, fh, fw)) {
         fprintf(stderr, "%s: failed to load image from '%s'\n", __func__, params.fname_inp.c_str());
         return 1;
     }
@@ -162,7 +135,7 @@ int main(int argc, char** argv) {
         printf("%s: %d frames, %d x %d -> %d patches: predict %.2f ms/frame, whole loop %.2f ms/frame (%.1f frames/s)\n", __func__, frames,
                FRAME_WIDTH, FRAME_HEIGHT, P, sum_predict / (frames - 1), sum_loop / (frames - 1), 1e3 * (frames - 1) / sum_loop);
     if (!params.image_out.empty()) {
-        if (write_ppm_from_bgr(params.image_out, combined, FRAME_HEIGHT, 2 * FRAME_WIDTH))
+        if (dinojpeg::imwrite_bgr(params.image_out, combined.data(), FRAME_HEIGHT, 2 * FRAME_WIDTH))
             fprintf(stderr, "%s: Saved image to: %s\n", __func__, params.image_out.c_str());
         else
             fprintf(stderr, "%s: failed to save image to '%s'\n", __func__, params.image_out.c_str());

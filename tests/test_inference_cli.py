@@ -70,14 +70,14 @@ def _build_cpp_inference(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "inference")
     libdir = os.path.join(root, "dinov2.cpp_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-I", os.path.join(root, "examples"),
                            os.path.join(root, "examples", "inference.cpp"), "-o", exe, os.path.join(libdir, "libdinov2_hip.so"),
                            f"-Wl,-rpath,{libdir}"])
     return exe
 
 
 def test_cpp_inference_builds_and_reports_errors(tmp_path):
-    """examples/inference.cpp (the reference's `inference` flow on the C++ shim, PPM instead of OpenCV codecs) builds with plain
+    """examples/inference.cpp (the reference's `inference` flow on the C++ shim, JPEG / PPM through examples/jpeg_codec.hpp instead of OpenCV codecs) builds with plain
     g++; usage and failure paths behave like the reference (unknown flag -> usage + exit 0; unreadable image -> message + 1)."""
     import subprocess
     exe = _build_cpp_inference(tmp_path)
@@ -138,7 +138,7 @@ def test_cpp_realtime_loop(golden_dir, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "realtime")
     libdir = os.path.join(root, "dinov2.cpp_amd")
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "realtime.cpp"),
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "examples"), os.path.join(root, "examples", "realtime.cpp"),
                            "-o", exe, "-L" + libdir, "-ldinov2_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"])
     gguf = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
     rng = np.random.default_rng(4)
@@ -192,3 +192,46 @@ def test_pca_visual_device_matches_host(golden_dir):
     a = inf.pca_visual(tok, rows, cols, rows * 14, cols * 14, session=sess).astype(np.int32)
     b = inf.pca_visual(tok, rows, cols, rows * 14, cols * 14).astype(np.int32)
     assert a.shape == (rows * 14, cols * 14, 3) and np.abs(a - b).max() <= 1
+
+
+@pytest.mark.gpu
+def test_reference_benchmark_script_commands_run_unchanged(pkg, golden_dir, tmp_path):
+    """/root/reference/scripts/benchmark.sh:55-100, the commands exactly as the script issues them, in the script's directory layout:
+    `cd build/`, `./bin/quantize ../ggml-model.gguf ../ggml-model-quant.gguf <id>`, `./bin/inference -c -m <model> -i ../assets/tench.jpg -t N`
+    with stderr through the script's own sed expression -- against `make -C dinov2.cpp_amd examples` binaries, a synthetic ViT-S/14 GGUF in
+    place of the converted checkpoint (no network) and tests/golden/tench.jpg = the reference's assets/tench.jpg (progressive JPEG, decoded by
+    examples/jpeg_codec.hpp)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "dinov2.cpp_amd"), "examples"], stdout=subprocess.DEVNULL)
+    work = tmp_path / "repo"
+    (work / "build" / "bin").mkdir(parents=True)
+    (work / "assets").mkdir()
+    for exe in ("inference", "quantize"):
+        shutil.copy(os.path.join(root, "build", "bin", exe), work / "build" / "bin" / exe)
+    shutil.copy(os.path.join(golden_dir, "tench.jpg"), work / "assets" / "tench.jpg")
+    pkg.synth.write_synthetic_gguf(str(work / "ggml-model.gguf"), "small", registers=0, num_classes=1000, seed=5)
+    sed = r"s/.*main: graph computation took ([0-9]+) ms.*/\1/p"
+    cwd = str(work / "build")
+
+    def graph_ms(model):
+        out = subprocess.run(f"./bin/inference -c -m {model} -i ../assets/tench.jpg -t 12 2>&1 | sed -En '{sed}'", shell=True, cwd=cwd,
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip().isdigit(), (out.stdout, out.stderr)
+        return int(out.stdout)
+
+    assert 0 <= graph_ms("../ggml-model.gguf") < 5000
+    full = subprocess.run("./bin/inference -c -m ../ggml-model.gguf -i ../assets/tench.jpg -t 12", shell=True, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert "loaded image '../assets/tench.jpg' (408 x 612)" in full.stderr and "preprocessed image (224 x 224)" in full.stderr, full.stderr
+    top = [ln for ln in full.stdout.splitlines() if ln.startswith(" > ")]
+    assert len(top) == 5
+    for q in (2, 8):  # q4_0, q8_0: benchmark.sh:60
+        r = subprocess.run(f"./bin/quantize ../ggml-model.gguf ../ggml-model-quant.gguf {q}", shell=True, cwd=cwd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert 0 <= graph_ms("../ggml-model-quant.gguf") < 5000
+    # the feature path writes the PCA picture as a JPEG (the reference's default output name) that a stock decoder reads
+    r = subprocess.run("./bin/inference -m ../ggml-model.gguf -i ../assets/tench.jpg", shell=True, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Saved image to: pca_visual.jpg" in r.stderr, r.stderr
+    from PIL import Image
+    assert np.asarray(Image.open(os.path.join(cwd, "pca_visual.jpg"))).shape == (420, 616, 3)
