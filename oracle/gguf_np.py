@@ -79,6 +79,14 @@ def dequantize(raw: np.ndarray, gtype: int, shape) -> np.ndarray:
     return w.astype(np.float32).reshape(shape)
 
 
+def block_mins(raw: np.ndarray, gtype: int, rows: int) -> np.ndarray:
+    """The per-block minimum `m` of a Q4_1 / Q5_1 tensor (block layout d f16 | m f16 | ...): float32 [rows, blocks per row]."""
+    assert gtype in (GGML_Q4_1, GGML_Q5_1)
+    _, bb = TYPE_LAYOUT[gtype]
+    blk = np.ascontiguousarray(raw, dtype=np.uint8).reshape(-1, bb)
+    return np.ascontiguousarray(blk[:, 2:4].copy().view(np.float16).astype(np.float32).reshape(rows, -1))
+
+
 # ----------------------------------------------------------------------------------------
 # reader
 # ----------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ _fp = C.POINTER(C.c_float)
 
 class _Layer(C.Structure):
     _fields_ = [(n, _fp) for n in ("norm1_w", "norm1_b", "qkv_w", "qkv_b", "o_w", "o_b", "ls1", "norm2_w",
-                                   "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2")]
+                                   "norm2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "ls2", "qkv_m", "o_m", "fc1_m", "fc2_m")]
 
 
 class _Model(C.Structure):
@@ -34,7 +34,7 @@ class _Model(C.Structure):
                 + [(n, C.c_int32) for n in ("act_round", "conv_round", "gelu_f16_lut", "pool_const_divisor",
                                             "pool_includes_registers", "attn_round")]
                 + [(n, _fp) for n in ("patch_w", "patch_b", "cls", "pos", "reg", "ln_w", "ln_b", "head_w", "head_b")]
-                + [("layer", C.POINTER(_Layer))])
+                + [("layer", C.POINTER(_Layer)), ("head_m", _fp)])
 
 
 def build(force: bool = False) -> str:
@@ -71,7 +71,8 @@ class OracleModel:
     """dino_model counterpart: hparams + name->f32 tensor map + numerics switches.
 
     quant_mode (only matters for quantised 2-D weights):
-      "ggml"    activations quantised to q8_0 blocks, weights dequantised exactly (ggml CPU semantics)
+      "ggml"    activations quantised to q8_0 blocks (Q4_0 / Q5_0 / Q8_0 weights) or q8_1 blocks (Q4_1 / Q5_1 weights: the block sum
+                s = f16(d * sum q) multiplies the weight block's minimum), weights dequantised exactly (ggml CPU semantics)
       "dequant" weights dequantised then ROUNDED TO F16, activations rounded to f16 -- the contract of a
                 dequant-on-load f16 MFMA path
     """
@@ -102,7 +103,7 @@ class OracleModel:
         quant = wt not in (G.GGML_F32, G.GGML_F16, G.GGML_BF16)
         if act_round is None:
             act_round = 0 if wt == G.GGML_F32 else 2 if wt == G.GGML_BF16 else 1 if not quant else \
-                (3 if quant_mode == "ggml" else 1)
+                ((4 if wt in (G.GGML_Q4_1, G.GGML_Q5_1) else 3) if quant_mode == "ggml" else 1)
         self._keep = []
 
         def w2d(name):
@@ -116,6 +117,13 @@ class OracleModel:
             a = np.ascontiguousarray(t[name].to_f32().reshape(-1))
             self._keep.append(a)
             return a
+
+        def wmin(name):  # block minima of a Q4_1 / Q5_1 weight for the Q8_1 dot product (act_round 4), else NULL
+            if act_round != 4 or t[name].gtype not in (G.GGML_Q4_1, G.GGML_Q5_1):
+                return _fp()
+            a = G.block_mins(t[name].raw, t[name].gtype, t[name].ne[1])
+            self._keep.append(a)
+            return _p(a)
 
         self.ffn_hidden = (t["encoder.layer.0.mlp.weights_out.weight"].ne[0] if self.swiglu
                            else t["encoder.layer.0.mlp.fc1.weight"].ne[1])
@@ -132,6 +140,8 @@ class OracleModel:
             ly.fc1_w, ly.fc1_b = _p(w2d(b + fc1 + ".weight")), _p(v(b + fc1 + ".bias"))
             ly.fc2_w, ly.fc2_b = _p(w2d(b + fc2 + ".weight")), _p(v(b + fc2 + ".bias"))
             ly.ls2 = _p(v(b + "layer_scale2.lambda1"))
+            ly.qkv_m, ly.o_m = wmin(b + "attention.attention.qkv.weight"), wmin(b + "attention.output.dense.weight")
+            ly.fc1_m, ly.fc2_m = wmin(b + fc1 + ".weight"), wmin(b + fc2 + ".weight")
         self._layers = layers
         m = self.c = _Model()
         m.hidden, m.layers, m.heads, m.registers = H, L, self.heads, self.registers
@@ -151,6 +161,7 @@ class OracleModel:
         m.ln_w, m.ln_b = _p(v("layernorm.weight")), _p(v("layernorm.bias"))
         if self.has_head:
             m.head_w, m.head_b = _p(w2d("classifier.weight")), _p(v("classifier.bias"))
+            m.head_m = wmin("classifier.weight")
         m.layer = layers
 
     def set(self, **kw):

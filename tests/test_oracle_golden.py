@@ -170,3 +170,51 @@ def test_oracle_matches_hf_at_vit_s_scale(tmp_path):
     # and with ggml's roundings switched on the result stays within the documented envelope of the f32 one
     r = OracleModel(path).forward(img, classify=True)
     assert np.abs(r["patch_tokens"] - final[1:]).max() < 2e-2
+
+
+def test_oracle_q8_1_activation_path_matches_ggml_vec_dot_q4_1_q8_1():
+    """SURVEY.md section 8(c), `mul_mat` row: Q4_1 / Q5_1 weights pair with Q8_1 activations -- blocks of 32 int8 with an f16 scale d AND
+    s = f16(d * sum q), which multiplies the weight block's minimum m (ggml-quants.c quantize_row_q8_1_ref / ggml_vec_dot_q4_1_q8_1:
+    sumf += d_w d_x sum_j q_w q_x + m_w s).  The oracle's linear_q (act_round 4) against that arithmetic restated on the integer blocks in
+    numpy; act_round 3 (Q8_0 activations: no s term) must differ from it by exactly the m_w (s - d sum q) terms."""
+    import ctypes as C
+    import numpy as np
+    from oracle import gguf_np as G
+    from oracle import oracle as O
+    gw = pytest.importorskip("dinov2_cpp_amd").gguf_writer
+    rng = np.random.default_rng(11)
+    T, N, K = 5, 7, 128
+    wf = (rng.standard_normal((N, K)) * 0.05 + 0.02).astype(np.float32)
+    raw = gw.quantize(wf, gw.GGML_Q4_1)                      # [N, K/32 * 20] bytes
+    blk = raw.reshape(N, K // 32, 20)
+    d_w = blk[:, :, 0:2].copy().view(np.float16).astype(np.float32)[..., 0]
+    m_w = blk[:, :, 2:4].copy().view(np.float16).astype(np.float32)[..., 0]
+    qs = blk[:, :, 4:]
+    q_w = np.concatenate([qs & 0xF, qs >> 4], axis=2).astype(np.int32)   # [N, nb, 32]
+    w_deq = G.dequantize(raw, G.GGML_Q4_1, (N, K))
+    assert np.array_equal(w_deq.reshape(N, K // 32, 32), (q_w * d_w[..., None] + m_w[..., None]).astype(np.float32))
+    x = (rng.standard_normal((T, K)) * 1.7).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    xb = x.reshape(T, K // 32, 32)
+    amax = np.abs(xb).max(-1)
+    d = (amax / np.float32(127.0)).astype(np.float32)
+    idv = np.where(d != 0, np.float32(1.0) / np.where(d != 0, d, 1), np.float32(0)).astype(np.float32)
+    v = xb * idv[..., None]
+    q_x = (np.sign(v) * np.floor(np.abs(v) + np.float32(0.5))).astype(np.int32)   # roundf
+    d_x = d.astype(np.float16).astype(np.float32)
+    s_x = (q_x.sum(-1).astype(np.float32) * d).astype(np.float16).astype(np.float32)
+    isum = np.einsum("nbj,tbj->tnb", q_w, q_x).astype(np.float64)
+    ggml = (isum * (d_w[None].astype(np.float64) * d_x[:, None].astype(np.float64)) + m_w[None].astype(np.float64) * s_x[:, None].astype(np.float64)).sum(-1) + bias
+    lib = O._lib()
+    fp = C.POINTER(C.c_float)
+    lib.oracle_linear_q_test.argtypes = [fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.oracle_linear_q_test.restype = None
+    out4, out3 = np.empty((T, N), np.float32), np.empty((T, N), np.float32)
+    mins = np.ascontiguousarray(G.block_mins(raw, G.GGML_Q4_1, N))
+    assert np.array_equal(mins, m_w)
+    p = lambda a: a.ctypes.data_as(fp)
+    lib.oracle_linear_q_test(p(x), p(w_deq), p(mins), p(bias), p(out4), T, N, K, 4)
+    lib.oracle_linear_q_test(p(x), p(w_deq), p(mins), p(bias), p(out3), T, N, K, 3)
+    assert np.abs(out4 - ggml).max() <= 2e-6 * np.abs(ggml).max()                       # f32 summation order only
+    corr = (m_w[None].astype(np.float64) * (s_x - d_x * q_x.sum(-1))[:, None]).sum(-1)    # what Q8_0 activations leave out
+    assert np.abs((out4 - out3) - corr).max() <= 2e-6 * np.abs(ggml).max() and np.abs(corr).max() > 1e-6
