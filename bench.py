@@ -58,11 +58,17 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense f16/bf16, /opt/skills/guides/MI355X_MICROARCH
 
 def commit_id() -> str:
     """The commit the measured tree is at: .head_sha (written by tools/gpurun_measure.sh before the snapshot travels to the GPU box, which
-    has no .git) or `git rev-parse` where a repository is present; "+dirty" when uncommitted changes were in the tree."""
+    has no .git), `git rev-parse` where a repository is present, else the id compiled into libdinov2_hip.so at build time
+    (dinov2_hip_build_id -- what the driver's box reports); "+dirty" when uncommitted changes were in the tree."""
     try:
         f = os.path.join(ROOT, ".head_sha")
         if os.path.exists(f):
             return open(f).read().strip() or "unknown"
+        if not os.path.exists(os.path.join(ROOT, ".git")):
+            from importlib import import_module
+            from __graft_entry__ import PKG_NAME, load_package
+            load_package()
+            return import_module(PKG_NAME + ".api").build_id() + " (library build id)"
         import subprocess
         sha = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip()
         dirty = subprocess.run(["git", "status", "--porcelain", "--untracked-files=no"], cwd=ROOT, capture_output=True, text=True, timeout=10).stdout.strip()
@@ -147,7 +153,7 @@ def group_front(api, path, devices, dt, B, S, num_classes, steps, windows, warmu
         return {"value": round(G * B * steps / med, 2), "unit": "images/sec", "ms_per_step": round(med / steps * 1e3, 3), "steps": steps, "windows": windows,
                 "window_values": [round(G * B * steps / w, 2) for w in win], "devices": list(devices), "global_batch": G * B,
                 "in_flight": 2, "host_buffers": "page-locked f32 [B, 3, S, S] in, f32 logits out",
-                "group_broadcast_ms": round(grp.broadcast_ms, 2) if G > 1 and grp.broadcast_ms >= 0 else None,
+                "group_broadcast_ms": round(grp.broadcast_ms, 2) if G > 1 and grp.broadcast_ms >= 0 else None, "topology": grp.topology,
                 "definition": "wall time around whole predict calls with the input upload and the result download inside (the reference's "
                               "inference.cpp:64-68), two batches in flight from one host thread"}
     finally:
@@ -516,8 +522,9 @@ def main():
     # FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md), collected by tools/hbm_traffic.sh over this same
     # command and committed under profiles/ (a PMC pass cannot run inside the timed process).
     traffic = None
+    traffic_src = None
     try:
-        tfile = next(f for f in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
+        tfile = next(f for f in ("r06_hbm_traffic.json", "r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json", "r01_hbm_traffic.json")
                      if os.path.exists(os.path.join(ROOT, "profiles", f)))
         tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
         # FFN-in at this shape runs the mixed 256/192-row launch (gemm.hip plan C): one kernel per GEMM -- gemm4.hip's since round 4
@@ -526,10 +533,12 @@ def main():
         hit = [v for sym in syms for k, v in tj.items() if sym in k][:1]
         if hit and args.model == "large" and B == 32 and not cfg["swiglu"]:
             traffic = round(hit[0]["hbm_bytes_per_launch_corrected"])
+            traffic_src = {"file": "profiles/" + tfile, "commit": tj.get("commit", "unknown"),
+                           "box": "the builder's measurement box of that round (gpurun), not this run's"}
     except Exception:
         traffic = None
     roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "frac": round(ach / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "traffic_note": "HBM-side bytes/launch from rocprofv3 FETCH_SIZE x2 + WRITE_SIZE (profiles/r0N_hbm_traffic.json, newest round); "
                                 "algorithmic bytes/launch = %d" % int(2 * M * H + 2 * H * F + 2 * M * F),
                 "flops_per_launch": flops_launch[dom], "avg_launch_ms": kernels.get(dom, {}).get("avg_ms"),
@@ -616,6 +625,19 @@ def main():
             host_leg["ratio_to_value"] = round(host_leg["value"] / value, 4)
         except Exception as e:  # a side measurement must not take the headline down
             host_leg = {"error": repr(e)}
+
+    # ---- N > 1: the OTHER multi-GPU front end in the same run: one process (this rank), all N devices behind
+    #      dinov2_hip_group_submit / _wait, host buffers in and out, while the other ranks idle at the final barrier -- so that the first
+    #      8-GPU run yields both front ends and `per_rank` from one driver command.  A side measurement: an error goes into the field.
+    group_leg = None
+    if world > 1 and not args.no_host_buffers:
+        try:
+            devs = [0] * world if dryrun else list(range(world))
+            with wd.stage("group front over %d devices (rank 0, one process)" % world, 900.0):
+                group_leg = group_front(api, path, devs, dt, B, S, num_classes, steps=max(4, min(args.steps, 10)), windows=3)
+            group_leg["ratio_to_value"] = round(group_leg["value"] / value, 4)
+        except BaseException as e:
+            group_leg = {"error": repr(e)}
 
     # ---- CPU baseline: the oracle (restatement of the reference graph) on the host cores, bounded sample ----
     cpu = None
@@ -707,7 +729,7 @@ def main():
         "p50_latency_ms_batch1_224x224": p50_224, "p99_latency_ms_batch1_224x224": p99_224,
         "p50_latency_ms_batch1_ln_fold": p50_fold, "p50_latency_ms_batch1_224x224_ln_fold": p50_224_fold,
         "ln_fold": os.environ.get("DINOV2_HIP_LN_FOLD", "0") not in ("0", ""),  # (the headline runs the library's default: off)
-        "two_sessions_images_per_sec": two_stream,
+        "two_sessions_images_per_sec": two_stream, "group_front": group_leg,
         "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         "load_s": round(load_s, 2), "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
         "broadcast_verified": bcast_ok, "config4": config4, "per_rank": per_rank,

@@ -76,6 +76,11 @@ def set_tuning(key, value):
         raise ValueError(f"unknown tuning key {key!r}")
 
 
+def build_id() -> str:
+    """The commit libdinov2_hip.so was built from (dinov2_hip_build_id)."""
+    return lib().dinov2_hip_build_id().decode()
+
+
 def gemm_plan(dtype, epilogue, M, N, K):
     """The kernel plan launch_gemm picks for a shape (text; no device needed)."""
     buf = C.create_string_buffer(256)
@@ -133,6 +138,7 @@ def lib():
     L.dinov2_hip_group_model.restype = vp
     L.dinov2_hip_group_broadcast_ms.argtypes = [vp]
     L.dinov2_hip_group_broadcast_ms.restype = C.c_double
+    L.dinov2_hip_group_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.dinov2_hip_group_predict.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, cp, sz]
     L.dinov2_hip_group_submit.argtypes = [vp, C.POINTER(Input), C.POINTER(Output), u32, C.POINTER(C.c_int64), cp, sz]
     L.dinov2_hip_group_wait.argtypes = [vp, C.c_int64, cp, sz]
@@ -152,6 +158,7 @@ def lib():
     fp = C.POINTER(C.c_float)
     L.dinov2_hip_op_gemm.argtypes = [i32, i32, fp, fp, fp, fp, C.c_int64, fp, i32, i32, i32, i32, i32, i32, i32, i32, i32,
                                      C.c_float]
+    L.dinov2_hip_build_id.restype = C.c_char_p
     L.dinov2_hip_op_gemm_resid_ln.argtypes = [i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32]
     L.dinov2_hip_op_gemm_ln_consumer.argtypes = [i32, i32, fp, fp, fp, fp, fp, C.c_float, fp, i32, i32, i32, i32, i32, C.c_float]
     L.dinov2_hip_op_ln_prepare.argtypes = [i32, fp, fp, fp, fp, i32, i32]
@@ -339,6 +346,8 @@ class Group:
         self.hparams = HParams()
         L.dinov2_hip_model_hparams(L.dinov2_hip_group_model(h, 0), C.byref(self.hparams))
         self.broadcast_ms = float(L.dinov2_hip_group_broadcast_ms(h))
+        buf = C.create_string_buffer(8192)
+        self.topology = buf.value.decode().splitlines() if L.dinov2_hip_group_describe(h, buf, len(buf)) == 0 else []
 
     def predict(self, images: np.ndarray, *, classify: bool = False, layout: int = RGB_CHW, topk: int = 0,
                 want=("cls", "patch_tokens", "logits", "probs")) -> dict:

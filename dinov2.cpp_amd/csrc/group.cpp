@@ -19,6 +19,7 @@
 // RCCL is loaded with dlopen on first use: single-GPU users of libdinov2_hip.so neither link nor load it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <chrono>
 #include <condition_variable>
@@ -98,6 +99,69 @@ struct Rccl {
 };
 Rccl g_rccl;
 std::mutex g_rccl_mu;
+
+// ---- host placement (round 6; unexercised on more than one physical GPU so far, hence defensive everywhere) ------------------------
+// A device's PCIe attachment: bus id, NUMA node and the CPUs local to it, read from sysfs (absent or empty inside some containers: then
+// nothing is known and nothing is bound).
+struct DevPlace {
+    std::string bdf, cpulist;
+    int numa = -1;
+};
+DevPlace device_place(int device) {
+    DevPlace p;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int)sizeof bdf, device) != hipSuccess) {
+        (void)hipGetLastError();
+        return p;
+    }
+    for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+    p.bdf = bdf;
+    auto slurp = [&](const char* leaf) {
+        std::string out;
+        const std::string path = std::string("/sys/bus/pci/devices/") + bdf + "/" + leaf;
+        if (FILE* f = fopen(path.c_str(), "r")) {
+            char buf[512];
+            if (fgets(buf, sizeof buf, f)) out = buf;
+            fclose(f);
+        }
+        while (!out.empty() && (out.back() == '\n' || out.back() == ' ')) out.pop_back();
+        return out;
+    };
+    const std::string nn = slurp("numa_node");
+    if (!nn.empty()) p.numa = atoi(nn.c_str());
+    p.cpulist = slurp("local_cpulist");
+    return p;
+}
+// The worker threads of a device run on the CPUs local to it (they issue its copies and launches; a thread on the far socket pays a
+// cross-socket hop per doorbell).  DINOV2_HIP_GROUP_NO_AFFINITY=1 leaves the threads where the scheduler puts them.
+void bind_to_device_cpus(int device) {
+    if (getenv("DINOV2_HIP_GROUP_NO_AFFINITY")) return;
+    const DevPlace p = device_place(device);
+    if (p.cpulist.empty()) return;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof allowed, &allowed) != 0) return;
+    const char* c = p.cpulist.c_str();
+    int n = 0;
+    while (*c) {  // "0-63,128-191"
+        char* e = nullptr;
+        const long a = strtol(c, &e, 10);
+        if (e == c) break;
+        long b = a;
+        c = e;
+        if (*c == '-') {
+            b = strtol(c + 1, &e, 10);
+            c = e;
+        }
+        for (long i = a; i <= b && i < CPU_SETSIZE; ++i)
+            if (i >= 0 && CPU_ISSET((int)i, &allowed)) {
+                CPU_SET((int)i, &want);
+                ++n;
+            }
+        if (*c == ',') ++c;
+    }
+    if (n > 0) (void)sched_setaffinity(0, sizeof want, &want);  // (never an empty set: the container may expose none of the local CPUs)
+}
 
 struct Job {
     dinov2_hip_input in{};
@@ -239,6 +303,7 @@ void run_job(dinov2_hip_group* g, int r, int l, int64_t k, const Job& job, int* 
 
 void worker(dinov2_hip_group* g, int r, int l) {
     (void)hipSetDevice(g->ranks[(size_t)r]->device);
+    bind_to_device_cpus(g->ranks[(size_t)r]->device);
     auto& ln = *g->ranks[(size_t)r]->lanes[(size_t)l];
     for (;;) {
         Job job;
@@ -367,51 +432,70 @@ extern "C" int dinov2_hip_group_create(const char* gguf_path, const dinov2_hip_g
         g->ranks.push_back(std::move(rk));
     }
     if (bcast) {
-        std::string why;
-        std::lock_guard<std::mutex> lk(g_rccl_mu);  // communicator setup is process-global state in RCCL
-        if (!g_rccl.load(&why)) {
-            set_err(err, errlen, "%s", why.c_str());
-            return DINOV2_HIP_ERR_HIP;
-        }
-        const int n = (int)devs.size();
-        std::vector<void*> comms((size_t)n, nullptr);
-        std::vector<hipStream_t> streams((size_t)n, nullptr);
-        int nrc = g_rccl.CommInitAll(comms.data(), n, devs.data());
-        if (nrc != 0) {
-            set_err(err, errlen, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(nrc));
-            return DINOV2_HIP_ERR_HIP;
-        }
-        bool ok = true;
-        for (int i = 0; i < n && ok; ++i)
-            ok = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamCreateWithFlags(&streams[(size_t)i], hipStreamNonBlocking) == hipSuccess;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (ok) {
-            // one message per rank: the whole arena (ViT-L f16 613 MB, ViT-g bf16 2.28 GB).  A ring broadcast over xGMI is bound
-            // by one link (~153 GB/s), so few large messages, never many small ones.
-            nrc = g_rccl.GroupStart();
-            for (int i = 0; i < n && nrc == 0; ++i) {
-                (void)hipSetDevice(devs[(size_t)i]);
-                dinov2_hip_model* m = g->ranks[(size_t)i]->model;
-                nrc = g_rccl.Broadcast(m->arena, m->arena, m->arena_bytes, /*ncclUint8*/ 1, /*root*/ 0, comms[(size_t)i], streams[(size_t)i]);
+        // Any failure in here -- no librccl, no communicator (peer access off, a fabric problem), a failed transfer -- degrades to "every
+        // device reads the file itself" with a line on stderr, unless DINOV2_HIP_GROUP_REQUIRE_RCCL asks for an error: the weights are
+        // identical either way, and this path has not yet run on more than one physical GPU.
+        std::string fail;
+        {
+            std::lock_guard<std::mutex> lk(g_rccl_mu);  // communicator setup is process-global state in RCCL
+            const int n = (int)devs.size();
+            std::vector<void*> comms((size_t)n, nullptr);
+            std::vector<hipStream_t> streams((size_t)n, nullptr);
+            int nrc = 0;
+            if (!g_rccl.load(&fail)) {
+                nrc = -1;
+            } else if ((nrc = g_rccl.CommInitAll(comms.data(), n, devs.data())) != 0) {
+                fail = std::string("ncclCommInitAll failed: ") + g_rccl.GetErrorString(nrc);
             }
-            const int erc = g_rccl.GroupEnd();
-            if (nrc == 0) nrc = erc;
+            bool ok = nrc == 0;
+            for (int i = 0; i < n && ok; ++i)
+                ok = hipSetDevice(devs[(size_t)i]) == hipSuccess && hipStreamCreateWithFlags(&streams[(size_t)i], hipStreamNonBlocking) == hipSuccess;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (ok) {
+                // one message per rank: the whole arena (ViT-L f16 613 MB, ViT-g bf16 2.28 GB).  A ring broadcast over xGMI is bound
+                // by one link (~153 GB/s), so few large messages, never many small ones.
+                nrc = g_rccl.GroupStart();
+                for (int i = 0; i < n && nrc == 0; ++i) {
+                    (void)hipSetDevice(devs[(size_t)i]);
+                    dinov2_hip_model* m = g->ranks[(size_t)i]->model;
+                    nrc = g_rccl.Broadcast(m->arena, m->arena, m->arena_bytes, /*ncclUint8*/ 1, /*root*/ 0, comms[(size_t)i], streams[(size_t)i]);
+                }
+                const int erc = g_rccl.GroupEnd();
+                if (nrc == 0) nrc = erc;
+                for (int i = 0; i < n; ++i) {
+                    (void)hipSetDevice(devs[(size_t)i]);
+                    if (hipStreamSynchronize(streams[(size_t)i]) != hipSuccess) ok = false;
+                }
+                if (!ok || nrc != 0) fail = std::string("weight broadcast failed: ") + (nrc != 0 ? g_rccl.GetErrorString(nrc) : "HIP stream error");
+            } else if (fail.empty()) {
+                fail = "could not create the broadcast streams";
+            }
+            g->broadcast_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             for (int i = 0; i < n; ++i) {
-                (void)hipSetDevice(devs[(size_t)i]);
-                if (hipStreamSynchronize(streams[(size_t)i]) != hipSuccess) ok = false;
+                if (streams[(size_t)i]) {
+                    (void)hipSetDevice(devs[(size_t)i]);
+                    (void)hipStreamDestroy(streams[(size_t)i]);
+                }
+                if (comms[(size_t)i]) (void)g_rccl.CommDestroy(comms[(size_t)i]);
             }
+            (void)hipGetLastError();
         }
-        g->broadcast_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        for (int i = 0; i < n; ++i) {
-            if (streams[(size_t)i]) {
-                (void)hipSetDevice(devs[(size_t)i]);
-                (void)hipStreamDestroy(streams[(size_t)i]);
+        if (!fail.empty()) {
+            if (getenv("DINOV2_HIP_GROUP_REQUIRE_RCCL")) {
+                set_err(err, errlen, "%s", fail.c_str());
+                return DINOV2_HIP_ERR_HIP;
             }
-            if (comms[(size_t)i]) (void)g_rccl.CommDestroy(comms[(size_t)i]);
-        }
-        if (!ok || nrc != 0) {
-            set_err(err, errlen, "weight broadcast failed: %s", nrc != 0 ? g_rccl.GetErrorString(nrc) : "HIP stream error");
-            return DINOV2_HIP_ERR_HIP;
+            fprintf(stderr, "dinov2_hip_group_create: %s -- every device reads the GGUF itself\n", fail.c_str());
+            g->broadcast_ms = -1.0;
+            for (size_t i = 1; i < devs.size(); ++i) {  // ranks > 0 were loaded without tensor data: load them again, with
+                dinov2_hip_model_free(g->ranks[i]->model);
+                g->ranks[i]->model = nullptr;
+                dinov2_hip_load_opts lo = o.load;
+                lo.device = devs[i];
+                lo.skip_tensor_data = 0;
+                const int rc = dinov2_hip_model_load(gguf_path, &lo, &g->ranks[i]->model, err, errlen);
+                if (rc != DINOV2_HIP_OK) return rc;
+            }
         }
     }
     g->nlanes = o.streams_per_device <= 0 ? 2 : o.streams_per_device > 4 ? 4 : o.streams_per_device;
@@ -444,6 +528,35 @@ extern "C" dinov2_hip_model* dinov2_hip_group_model(dinov2_hip_group* g, int32_t
 }
 
 extern "C" double dinov2_hip_group_broadcast_ms(const dinov2_hip_group* g) { return g ? g->broadcast_ms : -1.0; }
+
+// One line per device: ordinal, PCI bus id, NUMA node, local CPUs (what the device's worker threads are bound to), which of the group's
+// other devices it can reach peer to peer, and how the weights got there.  For logs and for callers that place their page-locked
+// buffers (dinov2_hip_host_alloc from a thread bound to the device's CPUs lands on its node by first touch).
+extern "C" int dinov2_hip_group_describe(const dinov2_hip_group* g, char* out, size_t cap) {
+    if (!g || !out || cap == 0) return DINOV2_HIP_ERR_INVALID;
+    std::string s;
+    for (size_t i = 0; i < g->ranks.size(); ++i) {
+        const int d = g->ranks[i]->device;
+        const DevPlace p = device_place(d);
+        char line[512];
+        snprintf(line, sizeof line, "device %d pci %s numa %d cpus %s peers", d, p.bdf.empty() ? "?" : p.bdf.c_str(), p.numa,
+                 p.cpulist.empty() ? "?" : p.cpulist.c_str());
+        s += line;
+        for (size_t j = 0; j < g->ranks.size(); ++j) {
+            const int e = g->ranks[j]->device;
+            int can = 0;
+            if (e != d && hipDeviceCanAccessPeer(&can, d, e) != hipSuccess) {
+                (void)hipGetLastError();
+                can = -1;
+            }
+            s += e == d ? " ." : can > 0 ? " y" : can == 0 ? " n" : " ?";
+        }
+        s += g->broadcast_ms >= 0 ? (i == 0 ? " weights file" : " weights rccl-broadcast") : " weights file";
+        s += "\n";
+    }
+    snprintf(out, cap, "%s", s.c_str());
+    return DINOV2_HIP_OK;
+}
 
 // `require_empty`: refuse (under the SAME hold of g->mu that would enqueue) when another ticket is still un-waited -- the blocking
 // dinov2_hip_group_predict's guard; checking it in one critical section and enqueuing in another let a concurrent submit slip in between

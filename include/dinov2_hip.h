@@ -175,6 +175,11 @@ int dinov2_hip_group_size(const dinov2_hip_group *group);
 dinov2_hip_model *dinov2_hip_group_model(dinov2_hip_group *group, int32_t rank);
 /* wall time of the load-time arena broadcast in ms; negative when every rank read the file itself */
 double dinov2_hip_group_broadcast_ms(const dinov2_hip_group *group);
+/* Where the group's devices sit: one text line per device -- ordinal, PCI bus id, NUMA node, local CPUs (its worker threads are bound
+ * to them; DINOV2_HIP_GROUP_NO_AFFINITY=1 turns that off), peer-to-peer reachability of the group's other devices (y / n), and whether
+ * its weights came from the file or from the RCCL broadcast (a broadcast that cannot be set up degrades to file reads with a line on
+ * stderr; DINOV2_HIP_GROUP_REQUIRE_RCCL=1 makes it an error instead). */
+int dinov2_hip_group_describe(const dinov2_hip_group *group, char *out, size_t cap);
 /* dino_predict over the whole group: host input [B, ...] (any dinov2_hip_layout), host outputs [B, ...]; returns when every
  * shard has landed.  B < G leaves the high ranks idle.  One call at a time per group; refused (DINOV2_HIP_ERR_INVALID, nothing
  * queued) while a ticket of dinov2_hip_group_submit has not been waited for.  Layout / height / width are checked before
@@ -237,6 +242,9 @@ int dinov2_hip_debug_hidden(dinov2_hip_session *session, const dinov2_hip_input 
                             char *err, size_t errlen);
 
 int dinov2_hip_abi_version(void);
+/* the commit the library was built from ("<12 hex digits>[+dirty]", "unknown" outside a git checkout): measurements taken where there is
+ * no repository next to the library (bench.py on a GPU box) stamp themselves with it */
+const char *dinov2_hip_build_id(void);
 
 /* -- Environment ----------------------------------------------------------------------------------------------------------
  * The library reads exactly seven environment variables; none is needed in normal use.
