@@ -76,6 +76,11 @@ def set_tuning(key, value):
         raise ValueError(f"unknown tuning key {key!r}")
 
 
+def reset_tuning(key):
+    """Back to the value the environment gave the switch when the library first read it (0 if none)."""
+    set_tuning(key, -1)
+
+
 def build_id() -> str:
     """The commit libdinov2_hip.so was built from (dinov2_hip_build_id)."""
     return lib().dinov2_hip_build_id().decode()

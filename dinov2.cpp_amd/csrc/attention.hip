@@ -258,8 +258,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #if DINO_ATT_LOADER
             glds16(kbase + off, sK + j * 8 * ROWB);
             glds16(vbase + (off ^ vswzj[j]), sV + j * 8 * ROWB);
-            continue;
-#endif
+#else
             glds16(kbase + off, sK + (j * NWV + wid) * 8 * ROWB);  // uniform base + 32-bit lane offset: scalar-base loads
             glds16(vbase + (off ^ vswz), sV + (j * NWV + wid) * 8 * ROWB);
 #if DINO_PREC & 8
@@ -267,6 +266,7 @@ __global__ __launch_bounds__(NWV * 64, QB == 2 ? 2 : (NWV == 8 ? 4 : 2)) void at
 #endif
 #if DINO_PREC & 16
             glds16(vbase + (size_t)3 * H * 2 + (off ^ vswz), sV + 4 * TILEB + (j * NWV + wid) * 8 * ROWB);
+#endif
 #endif
         }
     };

@@ -350,7 +350,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                             o[r] = E::from_f32(vq);
                         }
 #if DINO_PREC & 25
-                        {  // second word of q | k | v: columns [N, 2N) of the (6H-wide) row
+                        if (p.ldo >= 2 * N) {  // second word of q | k | v: columns [N, 2N) of the (6H-wide) row model.cpp allocates in these builds
+                                               // (a launch with a dense output -- dinov2_hip_op_gemm -- has nowhere to put it: ADVICE r5)
                             typename E::vec4 lo;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                             asm("" : "+v"(vq));
                             o[r] = E::from_f32(vq);
 #if DINO_PREC & 25
-                            if (col0 + r < N) ((T*)p.out)[(size_t)row * p.ldo + N + col0 + r] = E::from_f32(vq - E::to_f32(o[r]));
+                            if (col0 + r < N && p.ldo >= 2 * N) ((T*)p.out)[(size_t)row * p.ldo + N + col0 + r] = E::from_f32(vq - E::to_f32(o[r]));
 #endif
                         } else {
                             // ggml_gelu = f16 lookup table: table[f16(x)] = f16(gelu(f32(f16(x)))).  EXACTLY the expression of
@@ -625,12 +626,14 @@ hipError_t gemm_init() {
 // ---- testing aids, read from the environment ONCE (ADVICE r4 / VERDICT r4 item 7a: they used to be getenv() calls on every launch) -------
 namespace {
 std::atomic<int> g_tune[TUNE_COUNT];
+int g_tune_env[TUNE_COUNT];  // what the environment said at first use: what a negative value restores (tests leave the process as they found it)
 std::once_flag g_tune_once;
 void tune_init() {
     static const char* const names[TUNE_COUNT] = {"DINOV2_HIP_GEMM_GEN", "DINOV2_HIP_GEMM_TILE", "DINOV2_HIP_ATTN_V", "DINOV2_HIP_ATTN_NWV"};
     for (int k = 0; k < TUNE_COUNT; ++k) {
         const char* e = getenv(names[k]);
-        g_tune[k].store(e ? atoi(e) : 0, std::memory_order_relaxed);
+        g_tune_env[k] = e ? atoi(e) : 0;
+        g_tune[k].store(g_tune_env[k], std::memory_order_relaxed);
     }
 }
 }  // namespace
@@ -640,7 +643,7 @@ int tune_get(TuneKey k) {
 }
 void tune_set(TuneKey k, int v) {
     std::call_once(g_tune_once, tune_init);
-    g_tune[k].store(v, std::memory_order_relaxed);
+    g_tune[k].store(v < 0 ? g_tune_env[k] : v, std::memory_order_relaxed);
 }
 
 // ---- plan recording (gemm_plan_describe): with a sink installed the leaves of launch_gemm note their kernel instead of launching it ------

@@ -71,7 +71,9 @@ int dinov2_hip_op_clock_slots(uint64_t *out18);
 
 /* Testing aids.  The switches the library used to read from the environment on every launch (DINOV2_HIP_GEMM_GEN, DINOV2_HIP_GEMM_TILE,
  * DINOV2_HIP_ATTN_V, DINOV2_HIP_ATTN_NWV; include/dinov2_hip.h, "Environment") are read ONCE, on first use; a test that wants to flip one
- * inside a process calls the setter: key = "gemm_gen" | "gemm_tile" | "attn_v" | "attn_nwv", value 0 = the library's own choice.
+ * inside a process calls the setter: key = "gemm_gen" | "gemm_tile" | "attn_v" | "attn_nwv", value 0 = the library's own choice,
+ * a negative value = back to what the environment said when the library first looked (so a test leaves a `DINOV2_HIP_GEMM_GEN=2 pytest`
+ * run as it found it).
  * Not thread-safe against concurrent forwards on other threads in the sense that they may see either value. */
 int dinov2_hip_op_set_tuning(const char *key, int32_t value);
 int dinov2_hip_op_get_tuning(const char *key); /* -1: unknown key */

@@ -49,8 +49,8 @@ def test_tuning_switch_changes_the_plan_and_resets(api):
         api.set_tuning("gemm_tile", 128)
         assert api.gemm_plan(F16, EPI_GELU, 43968, 4096, 1024).startswith("small<")
     finally:
-        api.set_tuning("gemm_gen", 0)
-        api.set_tuning("gemm_tile", 0)
+        api.reset_tuning("gemm_gen")
+        api.reset_tuning("gemm_tile")
     assert api.gemm_plan(F16, EPI_GELU, 43968, 4096, 1024) == base
     with pytest.raises(ValueError):
         api.set_tuning("no_such_switch", 1)

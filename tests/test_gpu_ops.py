@@ -221,8 +221,8 @@ def test_attention_kernels_agree_bit_for_bit(api, T):
             assert api.lib().dinov2_hip_op_attention(F16, _p(qkv), _p(out), B, T, H, nh) == 0
             assert np.array_equal(outs["1"], out), nwv
     finally:
-        api.set_tuning("attn_v", 0)
-        api.set_tuning("attn_nwv", 0)
+        api.reset_tuning("attn_v")
+        api.reset_tuning("attn_nwv")
 
 
 def test_attention_online_softmax_rescale(api):
@@ -496,7 +496,7 @@ def _gen_case(api, rng, dt, epi, M, N, K, gens, expect):
             _gemm(api, dt, epi, A, W, bias, aux if epi == EPI_RESID else None, out, M, N, K, Nout, qcols=N // 4, qscale=0.125)
             outs[gen] = out
     finally:
-        api.set_tuning("gemm_gen", 0)
+        api.reset_tuning("gemm_gen")
     first = outs[gens[0]]
     assert np.isfinite(first).all()
     for gen in gens[1:]:
@@ -557,7 +557,7 @@ def test_gemm_generation_race_screen(api, gen, M, N, K, name):
             _gemm(api, F16, EPI_PLAIN, A, W, bias, None, out, M, N, K, N)
             assert np.array_equal(out, ref)
     finally:
-        api.set_tuning("gemm_gen", 0)
+        api.reset_tuning("gemm_gen")
 
 
 # ---- exhaustive sweeps of the activation epilogues -------------------------------------------------------------------
@@ -630,7 +630,7 @@ def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
         assert plan.startswith(name), plan
         _gemm(api, dt, EPI_GELU, A, W, None, None, out, x.size, N, 256, N)
     finally:
-        api.set_tuning(key, 0)
+        api.reset_tuning(key)
     assert (out == out[:, :1]).all()  # every column computed the same function of the same value
     got = out[:, 0]
     xd = x.astype(np.float64)
@@ -682,7 +682,7 @@ def test_swiglu_epilogue_exhaustive_silu(api, dt, impl):
         assert plan.startswith(name), plan
         _gemm(api, dt, EPI_SWIGLU, A, W, bias, None, out, x.size, 2 * F, 256, F)
     finally:
-        api.set_tuning(key, 0)
+        api.reset_tuning(key)
     assert (out == out[:, :1]).all()
     got = out[:, 0].astype(np.float64)
     xd = x.astype(np.float64)
@@ -741,7 +741,7 @@ def test_gemm_plan_coverage_case_bits(api, case):
         ref = x0.copy()
         _gemm(api, dt, epi, A, W, bias, auxv, ref, M, N, K, ldo, **kw)
     finally:
-        api.set_tuning("gemm_tile", 0)
+        api.reset_tuning("gemm_tile")
     assert np.array_equal(out, ref), (plan, forced_plan)
     if epi != EPI_PATCH and M > 100:
         small = x0[:100].copy()
