@@ -577,7 +577,7 @@ def _f16_ulps(a, b):
 def _record_sweep(name, **vals):
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "activation_sweeps_r05.json")
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "activation_sweeps_r06.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         cur = json.load(open(path)) if os.path.exists(path) else {}
@@ -615,7 +615,7 @@ def test_gelu_epilogue_exhaustive_f16_table(api, dt, impl):
     h for h >= 10 (ggml_gelu_f32; /root/reference/dinov2.cpp:567).  The epilogue evaluates the tanh form with v_exp_f32 / v_rcp_f32
     (1 ulp approximations), so an entry can differ from the exactly rounded table where the exact value lies within that error of an f16
     rounding boundary: the test COUNTS those entries, bounds them (<= 1 f16 ulp each) and records the counts in
-    gpurun_out/activation_sweeps_r05.json -- against the correctly rounded table AND against ggml's own f32-built table (the oracle's).  All three epilogue implementations (small-tile kernel, gemm2 / gemm4.hip) are
+    gpurun_out/activation_sweeps_r06.json -- against the correctly rounded table AND against ggml's own f32-built table (the oracle's).  All three epilogue implementations (small-tile kernel, gemm2 / gemm4.hip) are
     swept, each forced and asserted by plan name."""
     x = _all_finite_f16()
     N = 256

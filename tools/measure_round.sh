@@ -36,12 +36,15 @@ timeout 1800 bash tools/other_configs.sh; cp gpurun_out/bench_base_b1.json gpuru
 timeout 600 python bench.py --model small --no-cpu-baseline --steps 10 --warmup 3 > $O/bench_small_b32.json 2> $O/bench_small.err
 timeout 900 python tools/readme_table.py > $O/readme_table.log 2>&1; tail -12 $O/readme_table.log; cp gpurun_out/readme_table.json $O/ 2>/dev/null
 timeout 600 python tools/host_path.py > $O/host_path.log 2>&1; tail -12 $O/host_path.log; cp gpurun_out/host_path.json $O/
-cp gpurun_out/parity_r05.json $O/parity.json 2>/dev/null; cp gpurun_out/activation_sweeps_r05.json $O/activation_sweeps.json 2>/dev/null
+cp gpurun_out/parity_r06.json $O/parity.json 2>/dev/null; cp gpurun_out/activation_sweeps_r06.json $O/activation_sweeps.json 2>/dev/null
 # round 4: the N > 1 code path rehearsed on this one GPU (gloo, all ranks on device 0), the GEMM generations interleaved, the power-wall probes
 timeout 1500 python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1 --master-port 29777 bench.py --gpus 8 --steps 3 --warmup 1 --windows 2 --warm-seconds 0 --backend gloo --batch 8 --no-cpu-baseline --no-latency > $O/bench_n8_gloo_dryrun.json 2> $O/bench_n8_dryrun.err; tail -c 600 $O/bench_n8_gloo_dryrun.json
 timeout 900 bash tools/ab_gen.sh > $O/ab_gen.txt 2>&1; cat $O/ab_gen.txt
 [ -x tools/probes/mfma_wall.bin ] && timeout 120 tools/probes/mfma_wall.bin > $O/mfma_wall.txt 2>&1
 [ -x tools/probes/gemm4w_prof.bin ] && timeout 200 tools/probes/gemm4w_prof.bin > $O/gemm4w_probe.txt 2>&1
+# round 6: the LN-fold option against the default, interleaved (tools/ab_ln_fold.sh), and the per-launch micro-benchmark incl. its four launches
+timeout 900 bash tools/ab_ln_fold.sh > $O/ab_ln_fold.txt 2>&1; cat $O/ab_ln_fold.txt
+timeout 300 python tools/kernel_bench.py --iters 50 > $O/kernel_bench.txt 2>&1; cat $O/kernel_bench.txt
 # round 5: the C-ABI group front as the headline on this one device (and as a 4-entry duplicate-device group), section profiles of the parked generation 5
 timeout 600 python bench.py --front group --gpus 1 --steps 10 --warmup 2 --windows 3 > $O/bench_front_group_n1.json 2> $O/bench_front_group.err; tail -c 400 $O/bench_front_group_n1.json
 timeout 600 python bench.py --front group --gpus 4 --devices 0,0,0,0 --batch 8 --steps 5 --warmup 2 --windows 2 > $O/bench_front_group_dup4.json 2>> $O/bench_front_group.err
