@@ -147,12 +147,32 @@ static __device__ __forceinline__ void ln_row_finish(const LnAcc& a, float inv_h
 // register staging.  Same summation order, same bits.
 static __device__ __forceinline__ void ln_row_coeffs_lds(const float2* p, int gs, float inv_h, float eps, float& r, float& nrm) {
 #pragma clang fp contract(off)
+    // all twelve (or twenty-four) slots requested before the first add: the reads pipeline instead of taking one LDS round trip each
+    const float4* q = (const float4*)p;
+    float4 v[12];
+#pragma unroll
+    for (int g = 0; g < 6; ++g) v[g] = q[g];
+    if (gs > 12) {
+#pragma unroll
+        for (int g = 6; g < 12; ++g) v[g] = q[g];
+    }
     LnAcc a;
     a.S = a.Q = 0.0f;
-    for (int g = 0; g < gs; ++g) {  // (all gs slots, the zero ones included: the order and the bits of ln_row_add)
-        const float2 v = p[g];
-        a.S += v.x;
-        a.Q += v.y;
+#pragma unroll
+    for (int g = 0; g < 6; ++g) {  // (slot after slot, the zero ones included: the order and the bits of ln_row_add)
+        a.S += v[g].x;
+        a.Q += v[g].y;
+        a.S += v[g].z;
+        a.Q += v[g].w;
+    }
+    if (gs > 12) {
+#pragma unroll
+        for (int g = 6; g < 12; ++g) {
+            a.S += v[g].x;
+            a.Q += v[g].y;
+            a.S += v[g].z;
+            a.Q += v[g].w;
+        }
     }
     ln_row_finish(a, inv_h, eps, r, nrm);
 }

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     // done reading the buffer that tile kt+NST-1 is about to overwrite.  Raw s_barrier: __syncthreads() would drain vmcnt.
     constexpr int LPT = KSUB * (AI + BI);  // glds instructions per wave per stage
     static_assert((NST - 2) * LPT < 64, "vmcnt is 6 bits");
+    static_assert(!LNC || (NST - 1) * LPT < 64, "vmcnt is 6 bits (LN consumers wait with every first stage in flight)");
     const int nk = (K / BK) / KSUB;
     // LN consumers: the partial sums of this tile's rows ([BM][K / 64] x (sum, sum of squares)) go to LDS behind the ring by LDS-DMA,
     // AHEAD of the first stages (so every counted wait of the K loop covers them); they are turned into coefficients after the loop.
@@ -188,6 +189,22 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
         if (t < nk) stage(t, t);
+    // LN consumers: the LayerNorm coefficients (r, -mean r) of this lane's MREP rows, computed while the first stages are still in flight:
+    // the statistics were requested before them, so a wait that leaves exactly the stages' requests outstanding (and a barrier: other
+    // waves fetched other rows) is enough.  The four 16-lane groups each finalise ONE of the wave tile's 16-row blocks; the others come
+    // by lane exchange.
+    float lnr[LNC ? MREP : 1], lnn[LNC ? MREP : 1];
+    if constexpr (LNC) {
+        if (nk >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((NST - 1) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        float r1, n1;
+        ln_row_coeffs_lds(lnst + (size_t)(wm * WTM + (fh % MREP) * 16 + fr) * p.ln_gs, p.ln_gs, 1.0f / (float)K, p.ln_eps, r1, n1);
+#pragma unroll
+        for (int i = 0; i < MREP; ++i) {
+            lnr[i] = __shfl(r1, fr + 16 * i);
+            lnn[i] = __shfl(n1, fr + 16 * i);
+        }
+    }
     int buf = 0, nbuf = NST - 1;
     DINO_SP(0)
     for (int kt = 0; kt < nk; ++kt) {
@@ -225,19 +242,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         asm volatile("s_nop 0" : "+v"(acc[0][0]));  // the section ends when the last MFMA chain's first link has issued, not retired
 #endif
         DINO_SP(3)
-    }
-
-    // LN consumers: the LayerNorm coefficients (r, -mean r) of this lane's MREP rows.  The four 16-lane groups each finalise ONE of the
-    // wave tile's 16-row blocks; the others come by lane exchange.
-    float lnr[LNC ? MREP : 1], lnn[LNC ? MREP : 1];
-    if constexpr (LNC) {
-        float r1, n1;
-        ln_row_coeffs_lds(lnst + (size_t)(wm * WTM + (fh % MREP) * 16 + fr) * p.ln_gs, p.ln_gs, 1.0f / (float)K, p.ln_eps, r1, n1);
-#pragma unroll
-        for (int i = 0; i < MREP; ++i) {
-            lnr[i] = __shfl(r1, fr + 16 * i);
-            lnn[i] = __shfl(n1, fr + 16 * i);
-        }
     }
 
     // ---- epilogue: acc[i][j][r] is C[row, col] with
