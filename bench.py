@@ -698,6 +698,10 @@ def main():
                # (activations quantised to q8_0 blocks as well), where the stated bound is 2e-2
                "parity_bound": f"max|d_logit| <= {parity_bound(args):g} * max(1, max|logit|)",
                "within_bound": bool(dl <= parity_bound(args) * max(1.0, big)),
+               # north_star's wording read literally -- an ABSOLUTE 1e-3 on the logits -- next to the stated (relative) bound.  It is NOT
+               # reliably met and cannot be from this side: the ggml-mode oracle is itself 0.96e-3 (mean over images; worst 1.09e-3) from exact
+               # arithmetic on this model, i.e. the contract's own f16 roundings already use the whole absolute budget (profiles/r05_parity_attribution.md)
+               "within_bound_absolute_1e-3": bool(dl <= 1e-3),
                "max_abs_logit_diff_vs_exact": None if not exact else exact.get("max_abs_logit_diff_vs_exact"),
                "hip_over_worst_ggml_style": None if not exact else exact.get("hip_over_worst_ggml_style"),
                "distance_to_exact": exact}
