@@ -264,8 +264,9 @@ const char *dinov2_hip_build_id(void);
  *   DINOV2_HIP_GEMM_TILE=128|256   the small-tile kernel only / 256-row persistent tiles only.
  *   DINOV2_HIP_GEMM_GEN=2|4  which generation of the persistent GEMM runs the 256-row / mixed / one-tile-per-workgroup plans -- 2 = gemm2.hip
  *                            (eight waves, barrier-separated sections), 4 = gemm4.hip (four waves, hand-ordered K loop; the default for
- *                            K >= 1 024).  Both give every row the same bits.  (5 = the parked two-workgroups-per-CU generation, only
- *                            in the opt-in build `make -C dinov2.cpp_amd g5`: profiles/r05_gemm5.md.)
+ *                            K >= 1 024).  Both give every row the same bits.  (The LN-fold epilogues exist in gemm4.hip and the small-tile kernel only.)
+ *   DINOV2_HIP_LN_FOLD=0|1   what dinov2_hip_load_opts.ln_fold = 0 ("the library's choice") resolves to; unset: off.
+ *   DINOV2_HIP_GROUP_NO_AFFINITY=1  the group's worker threads are not bound to the CPUs local to their device.
  *   DINOV2_HIP_GROUP_REQUIRE_RCCL=1  dinov2_hip_group_create fails when librccl cannot be loaded instead of letting every device
  *                            read the GGUF itself.
  * (DINOV2_HIP_LIB, read by the Python binding only, points it at another build of this library.) */
