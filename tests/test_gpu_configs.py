@@ -130,7 +130,7 @@ def test_config3_forward_is_bitwise_repeatable(api, pkg, ggufs):
         assert np.array_equal(out["patch_tokens"], ref["patch_tokens"])
 
 
-@pytest.mark.parametrize("wtype", ["q8_0", "q4_0"])
+@pytest.mark.parametrize("wtype", ["q8_0", "q4_0", "q4_1"])
 def test_config5_vit_l_quantised_full_size(api, pkg, ggufs, wtype):
     """BASELINE configs[4] at ViT-L size: q8_0 / q4_0 GGUF -> dequantised on the device at load -> f16 MFMA path, all 24
     layers, against BOTH oracle contracts: "dequant" (the HIP path's own: f16 weights x f16 activations) at the f16 bound, and
@@ -138,7 +138,7 @@ def test_config5_vit_l_quantised_full_size(api, pkg, ggufs, wtype):
     path = ggufs("large", wtype)
     imgs = pkg.synth.synthetic_images(2, 518, 518, seed=5)
     model = api.Model(path, classify=True)
-    assert model.hparams.weight_type == {"q8_0": 8, "q4_0": 2}[wtype]
+    assert model.hparams.weight_type == {"q8_0": 8, "q4_0": 2, "q4_1": 3}[wtype]  # (q4_1: the oracle's "ggml" mode pairs it with Q8_1 activations)
     got = api.Session(model).predict(imgs, classify=True)
     same = OracleModel(path, quant_mode="dequant").forward(imgs[1], classify=True)
     ggml = OracleModel(path, quant_mode="ggml").forward(imgs[1], classify=True)
