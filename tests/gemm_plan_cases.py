@@ -154,6 +154,104 @@ COVERAGE_CASES = [
 ]
 
 
+# ---- the LN-fold launches (csrc/kernels.h epilogues 6 .. 9; csrc/model.cpp forward() with dinov2_hip_load_opts.ln_fold) ----
+EPI_RESID_LN, EPI_QKV_LN, EPI_GELU_LN, EPI_SWIGLU_LN = 6, 7, 8, 9
+
+
+def model_gemms_ln(name, batch, side, registers):
+    H, F, swiglu = MODELS[name]
+    T = (side // 14) ** 2 + 1 + registers
+    M = batch * T
+    return [(EPI_QKV_LN, M, 3 * H, H), (EPI_RESID_LN, M, H, H), (EPI_RESID_LN, M, H, F), (EPI_SWIGLU_LN, M, 2 * F, H) if swiglu else (EPI_GELU_LN, M, F, H)]
+
+
+def reachable_ln(api, dtypes=(F16, BF16)):
+    found = {}
+    for name in MODELS:
+        for b in BATCHES:
+            for side in SIDES:
+                for r in REGISTERS:
+                    for epi, M, N, K in model_gemms_ln(name, b, side, r):
+                        if M * max(N, K) * 2 >= 1 << 32:
+                            continue
+                        for dt in dtypes:
+                            for leaf in api.gemm_plan(dt, epi, M, N, K).split(";"):
+                                key = (leaf, epi, dt)
+                                if key not in found or M * N * K < found[key][0] * found[key][1] * found[key][2]:
+                                    found[key] = (M, N, K)
+    return found
+
+
+# one problem per reachable (leaf, LN epilogue, dtype), generated like COVERAGE_CASES (`python tests/gemm_plan_cases.py`); run by
+# tests/test_gpu_ln_fold.py::test_ln_plan_coverage_case_bits
+LN_COVERAGE_CASES = [
+    (0, 6, 257, 384, 384),  # small<32x64,w1x4,st3,ks2>
+    (1, 6, 257, 384, 384),  # small<32x64,w1x4,st3,ks2>
+    (0, 7, 257, 1152, 384),  # small<32x64,w1x4,st3,ks2>
+    (1, 7, 257, 1152, 384),  # small<32x64,w1x4,st3,ks2>
+    (0, 8, 257, 1536, 384),  # small<32x64,w1x4,st3,ks2>
+    (1, 8, 257, 1536, 384),  # small<32x64,w1x4,st3,ks2>
+    (0, 6, 1370, 384, 384),  # small<64x64,w2x4,st3,ks2>
+    (1, 6, 1370, 384, 384),  # small<64x64,w2x4,st3,ks2>
+    (0, 7, 514, 1152, 384),  # small<64x64,w2x4,st3,ks2>
+    (1, 7, 514, 1152, 384),  # small<64x64,w2x4,st3,ks2>
+    (0, 8, 514, 1536, 384),  # small<64x64,w2x4,st3,ks2>
+    (1, 8, 514, 1536, 384),  # small<64x64,w2x4,st3,ks2>
+    (0, 6, 2740, 384, 384),  # small<64x128,w2x4,st3,ks2>
+    (1, 6, 2740, 384, 384),  # small<64x128,w2x4,st3,ks2>
+    (0, 7, 1028, 1152, 384),  # small<64x128,w2x4,st3,ks2>
+    (1, 7, 1028, 1152, 384),  # small<64x128,w2x4,st3,ks2>
+    (0, 8, 1028, 1536, 384),  # small<64x128,w2x4,st3,ks2>
+    (1, 8, 1028, 1536, 384),  # small<64x128,w2x4,st3,ks2>
+    (0, 8, 1370, 1536, 384),  # gemm4_short<64>
+    (1, 8, 1370, 1536, 384),  # gemm4_short<64>
+    (0, 6, 5480, 384, 384),  # small<64x128,w2x2,st3,ks1>
+    (1, 6, 5480, 384, 384),  # small<64x128,w2x2,st3,ks1>
+    (0, 7, 2056, 1152, 384),  # small<64x128,w2x2,st3,ks1>
+    (1, 7, 2056, 1152, 384),  # small<64x128,w2x2,st3,ks1>
+    (0, 7, 2740, 1152, 384),  # small<64x128,w2x2,st2,ks1>
+    (1, 7, 2740, 1152, 384),  # small<64x128,w2x2,st2,ks1>
+    (0, 6, 8224, 384, 384),  # small<64x128,w2x2,st2,ks1>
+    (1, 6, 8224, 384, 384),  # small<64x128,w2x2,st2,ks1>
+    (0, 8, 2740, 1536, 384),  # gemm4_short<96>
+    (1, 8, 2740, 1536, 384),  # gemm4_short<96>
+    (0, 7, 1028, 2304, 768),  # gemm4_short<64>
+    (1, 7, 1028, 2304, 768),  # gemm4_short<64>
+    (0, 8, 5480, 1536, 384),  # gemm4<256>
+    (1, 8, 5480, 1536, 384),  # gemm4<256>
+    (0, 9, 257, 8192, 1536),  # gemm4_short<64>
+    (1, 9, 257, 8192, 1536),  # gemm4_short<64>
+    (0, 7, 8224, 1152, 384),  # small<128x128,w2x2,st2,ks1>
+    (1, 7, 8224, 1152, 384),  # small<128x128,w2x2,st2,ks1>
+    (0, 7, 2056, 2304, 768),  # gemm4_short<96>
+    (1, 7, 2056, 2304, 768),  # gemm4_short<96>
+    (0, 7, 10960, 1152, 384),  # gemm4<256>;small<64x128,w2x4,st3,ks2>
+    (1, 7, 10960, 1152, 384),  # gemm4<256>;small<64x128,w2x4,st3,ks2>
+    (0, 7, 2740, 2304, 768),  # gemm4_short<128>
+    (1, 7, 2740, 2304, 768),  # gemm4_short<128>
+    (0, 8, 2056, 3072, 768),  # gemm4_short<128>
+    (1, 8, 2056, 3072, 768),  # gemm4_short<128>
+    (0, 6, 43840, 384, 384),  # gemm4<256>;small<64x128,w2x2,st2,ks1>
+    (1, 6, 43840, 384, 384),  # gemm4<256>;small<64x128,w2x2,st2,ks1>
+    (0, 9, 514, 8192, 1536),  # gemm4_short<96>
+    (1, 9, 514, 8192, 1536),  # gemm4_short<96>
+    (0, 8, 16448, 1536, 384),  # gemm4_mixed<256+192>
+    (1, 8, 16448, 1536, 384),  # gemm4_mixed<256+192>
+    (0, 6, 87680, 384, 384),  # gemm4_mixed<256+192>;small<128x128,w2x2,st2,ks1>
+    (1, 6, 87680, 384, 384),  # gemm4_mixed<256+192>;small<128x128,w2x2,st2,ks1>
+    (0, 9, 1028, 8192, 1536),  # gemm4<256>
+    (1, 9, 1028, 8192, 1536),  # gemm4<256>
+    (0, 7, 43840, 1152, 384),  # gemm4_mixed<256+192>;small<64x128,w2x2,st2,ks1>
+    (1, 7, 43840, 1152, 384),  # gemm4_mixed<256+192>;small<64x128,w2x2,st2,ks1>
+    (0, 9, 2056, 8192, 1536),  # gemm4<256>;small<64x128,w4x2,st3,ks2>
+    (1, 9, 2056, 8192, 1536),  # gemm4<256>;small<64x128,w4x2,st3,ks2>
+    (0, 9, 2740, 8192, 1536),  # gemm4_mixed<256+192>
+    (1, 9, 2740, 8192, 1536),  # gemm4_mixed<256+192>
+    (0, 9, 16704, 8192, 1536),  # gemm4<256>;small<64x128,w2x2,st3,ks1>
+    (1, 9, 16704, 8192, 1536),  # gemm4<256>;small<64x128,w2x2,st3,ks1>
+]
+
+
 def cases_leaves(api, cases):
     got = set()
     for dt, epi, M, N, K in cases:
@@ -173,6 +271,17 @@ if __name__ == "__main__":
     need = reachable(api)
     print(f"# {len(need)} reachable (leaf, epilogue, dtype) combinations")
     # greedy: smallest problems first; one case may cover several leaves (split plans)
+    chosen, have = [], set()
+    for key, (M, N, K) in sorted(need.items(), key=lambda kv: kv[1][0] * kv[1][1] * kv[1][2]):
+        if key in have:
+            continue
+        case = (key[2], key[1], M, N, K)
+        chosen.append(case)
+        have |= cases_leaves(api, [case])
+    for c in chosen:
+        print(f"    {c},  # {api.gemm_plan(*c)}")
+    need = reachable_ln(api)
+    print(f"# LN fold: {len(need)} reachable (leaf, epilogue, dtype) combinations")
     chosen, have = [], set()
     for key, (M, N, K) in sorted(need.items(), key=lambda kv: kv[1][0] * kv[1][1] * kv[1][2]):
         if key in have:

@@ -7,7 +7,7 @@ import re
 
 import pytest
 
-from gemm_plan_cases import BF16, COVERAGE_CASES, EPI_GELU, EPI_PLAIN, EPI_QKV, EPI_RESID, F16, cases_leaves, reachable
+from gemm_plan_cases import BF16, COVERAGE_CASES, EPI_GELU, EPI_PLAIN, EPI_QKV, EPI_RESID, F16, LN_COVERAGE_CASES, cases_leaves, reachable, reachable_ln
 
 LEAF = re.compile(r"^(gemm2<(128|192|256)>|gemm2_mixed<256\+192>|gemm4<256>|gemm4_mixed<256\+192>|gemm4_short<(64|96|128)>|small<\d+x\d+,w\dx\d,st\d,ks\d>)$")
 
@@ -32,6 +32,16 @@ def test_cases_are_current_and_not_padded(api):
     for case in COVERAGE_CASES:
         got = cases_leaves(api, [case])
         assert got and got <= set(need), case
+
+
+def test_every_reachable_ln_fold_plan_is_covered(api):
+    """The same for the LN-fold launches (epilogues 6 .. 9; forward() with ln_fold): every (kernel, epilogue, dtype) a model of the family can
+    reach with the option on is run by tests/test_gpu_ln_fold.py::test_ln_plan_coverage_case_bits, and the list holds nothing stale."""
+    need = set(reachable_ln(api))
+    have = cases_leaves(api, LN_COVERAGE_CASES)
+    assert not (need - have), sorted(need - have)[:10]
+    assert not (have - need), sorted(have - need)[:10]
+    assert all(leaf.startswith(("gemm4", "small<")) for leaf, _, _ in need)  # (the LN epilogues do not exist in gemm2.hip)
 
 
 def test_plan_query_refuses_what_launch_gemm_refuses(api):

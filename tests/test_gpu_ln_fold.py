@@ -208,6 +208,48 @@ def test_ln_consumer_plans_cover_gemm4_and_small(api):
     assert plans[(261, 1536, 384)].startswith("small<") and plans[(300, 384, 128)].startswith("small<")
 
 
+import sys  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gemm_plan_cases import LN_COVERAGE_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", LN_COVERAGE_CASES, ids=lambda c: "dt%d-epi%d-%dx%dx%d" % c)
+def test_ln_plan_coverage_case_bits(api, case):
+    """One problem per (kernel, LN epilogue, dtype) the dispatcher can reach for the DINOv2 family with the fold on (the list is generated
+    from the library's own plan query; tests/test_gemm_plans.py checks it for completeness on the CPU).  Producers: x = the plain residual
+    epilogue's bits, xg and the row statistics exact functions of x.  Consumers: every 100-row copy carries the bits of a 100-row launch."""
+    dt, epi, M, N, K = case
+    rng = np.random.default_rng(M + 3 * N + 7 * K + 11 * epi + dt)
+    X = _round(rng.standard_normal((100, K)), dt)
+    A = np.ascontiguousarray(np.tile(X, ((M + 99) // 100, 1))[:M])
+    W = _round(rng.standard_normal((N, K)) * 0.05, dt)
+    last = M - 100 - M % 100 if M >= 200 else 0
+    if epi == EPI_RESID_LN:
+        bias, ls = rng.standard_normal(N).astype(np.float32), (rng.standard_normal(N) * 0.3).astype(np.float32)
+        gamma = (rng.standard_normal(N) * 0.3 + 1).astype(np.float32)
+        x0 = np.ascontiguousarray(np.tile((rng.standard_normal((100, N)) * 2 + 0.4).astype(np.float32), ((M + 99) // 100, 1))[:M])
+        x, xg, st = _resid_ln(api, dt, A, W, bias, ls, gamma, x0)
+        ref = x0.copy()
+        assert api.lib().dinov2_hip_op_gemm(dt, EPI_RESID, _p(A), _p(W), _p(bias), _p(ls), N, _p(ref), M, N, M, N, K, 0, 0, 0, 0, 1.0) == 0
+        assert np.array_equal(x, ref)
+        assert np.array_equal(xg, _round(x * gamma, dt))
+        assert np.array_equal(st, tree_stats(x))
+        if M >= 200:
+            assert np.array_equal(st[last:last + 100], st[:100]) and np.array_equal(xg[last:last + 100], xg[:100])
+        return
+    s, c = (rng.standard_normal(N) * 0.5).astype(np.float32), rng.standard_normal(N).astype(np.float32)
+    st100 = tree_stats((rng.standard_normal((100, K)) * 2 + 0.3).astype(np.float32))
+    st = np.ascontiguousarray(np.tile(st100, ((M + 99) // 100, 1, 1))[:M])
+    oc = N // 2 if epi == EPI_SWIGLU_LN else N
+    out = _consumer(api, dt, epi, A, W, s, c, st, oc, qcols=N // 3, qscale=0.18)
+    small = _consumer(api, dt, epi, X, W, s, c, st100, oc, qcols=N // 3, qscale=0.18)
+    assert np.isfinite(out).all()
+    assert np.array_equal(small, out[:100])
+    if M >= 200:
+        assert np.array_equal(out[last:last + 100], out[:100])
+
+
 # ---- end to end ---------------------------------------------------------------------------------------------------------------------------
 def _rel(a, b):
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
