@@ -144,7 +144,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     const bool vec_ok = EB != EPI_SWIGLU && EPI != EPI_PATCH && n0 + BN <= N && (p.ldo & 3) == 0 && (p.qcols & 3) == 0 &&
                         (((size_t)p.bias | (size_t)p.aux | (size_t)p.ln_s | (size_t)p.ln_c | (size_t)p.ln_gamma) & 15) == 0;
     // bias4: the additive per-column term (LN consumers: c[n], which contains the bias); lns4: LN consumers' s[n]
-    f32x4 bias4[NREP], aux4[NREP], lns4[LNC ? NREP : 1], xin4[EB == EPI_RESID ? MREP : 1][NREP];
+    f32x4 bias4[NREP], aux4[NREP], lns4[LNC ? NREP : 1], gam4[EPI == EPI_RESID_LN ? NREP : 1], xin4[EB == EPI_RESID ? MREP : 1][NREP];
     if (vec_ok) {
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
@@ -155,6 +155,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             } else {
                 bias4[jn] = p.bias ? *(const f32x4*)(p.bias + col0) : f32x4{0.f, 0.f, 0.f, 0.f};
             }
+            if constexpr (EPI == EPI_RESID_LN) gam4[jn] = *(const f32x4*)(p.ln_gamma + col0);
             if constexpr (EB == EPI_RESID) {
                 aux4[jn] = *(const f32x4*)(p.aux + col0);
 #pragma unroll
@@ -293,6 +294,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         for (int jn = 0; jn < NREP; ++jn) {
             asm volatile("" ::"v"(bias4[jn]));
             if constexpr (LNC) asm volatile("" ::"v"(lns4[jn]));
+            if constexpr (EPI == EPI_RESID_LN) asm volatile("" ::"v"(gam4[jn]));
             if constexpr (EB == EPI_RESID) {
                 asm volatile("" ::"v"(aux4[jn]));
 #pragma unroll
@@ -305,8 +307,6 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int jn = 0; jn < NREP; ++jn) {
             const int col0 = colb + jn * 16;
-            f32x4 gam4 = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (EPI == EPI_RESID_LN) gam4 = *(const f32x4*)(p.ln_gamma + col0);
 #pragma unroll
             for (int i = 0; i < MREP; ++i) {
                 const int row = rowb + i * 16;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                         typename E::vec4 og;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float g = xn[r] * gam4[r];
+                            float g = xn[r] * gam4[EPI == EPI_RESID_LN ? jn : 0][r];
                             asm("" : "+v"(g));  // f32 product first, then the rounding (as everywhere)
                             og[r] = E::from_f32(g);
                         }
