@@ -262,6 +262,11 @@ def main():
             with wd.stage("first barrier (communicator creation over xGMI)", args.dist_timeout + 30):
                 dist.barrier()  # forces the communicator (and the banner) now
                 torch.cuda.synchronize()
+            # The LAST rendezvous goes through a second, CPU-side (gloo) group with a long timeout: ranks != 0 reach it minutes before rank 0
+            # (which still has its per-kernel profile, the latency legs and -- round 6 -- the group front over all N devices to run), and an
+            # RCCL barrier would (a) time out after --dist-timeout and take the whole job down, (b) keep a spinning kernel on every other GPU
+            # while rank 0's group front measures them.
+            tail_pg = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=3600))
         finally:
             try:
                 ctypes.CDLL(None).fflush(None)
@@ -467,7 +472,8 @@ def main():
 
     if rank != 0:
         if dist is not None:
-            dist.barrier()
+            torch.cuda.synchronize()
+            dist.barrier(group=tail_pg)
             dist.destroy_process_group()
         return
 
@@ -750,7 +756,7 @@ def main():
         pass
     print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.barrier(group=tail_pg)
         dist.destroy_process_group()
 
 
