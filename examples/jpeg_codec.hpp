@@ -154,6 +154,7 @@ private:
             int code = 0, k = 0;  // figures C.1 - C.3, F.15
             for (int i = 0; i < 512; ++i) h.lookup[i] = 0;
             for (int l = 1; l <= 16; ++l) {
+                if (code + counts[l] > (1 << l)) return fail("over-subscribed Huffman table");
                 h.valptr[l] = k;
                 h.mincode[l] = code;
                 for (int i = 0; i < counts[l]; ++i, ++k, ++code)
