@@ -820,7 +820,7 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
             best = -1.0;
         } else {
             if (t256 < 192 && costE < best) { plan = 'E'; best = costE; }  // far from filling the chip with big tiles
-            if (split_ok && !ln && t192 >= 192 && rnd(t192) * 0.79 < best - 0.02) { plan = 'B'; best = rnd(t192) * 0.79; }
+            if (split_ok && t192 >= 192 && rnd(t192) * 0.79 < best - 0.02) { plan = 'B'; best = rnd(t192) * 0.79; }
         }
         const long R = t256 / 256;
         const int panels1 = (int)(R * 256 / ntn);
@@ -858,11 +858,17 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         // for the 2-byte epilogues (profiles/r04_gemm4w.md section 6).  DINOV2_HIP_GEMM_GEN=2 keeps plan F.
         {
             const bool two_byte = eb == EPI_QKV || eb == EPI_GELU || eb == EPI_SWIGLU;
-            if (two_byte && !forced && gen != 2 && gemm4_ok(epi, a) && (gen == 4 || ln || a.K >= 1024)) {
+            if ((two_byte || epi == EPI_RESID_LN) && !forced && gen != 2 && gemm4_ok(epi, a) && (gen == 4 || ln || a.K >= 1024)) {
                 int ni = 0;
                 for (int c = 2; c <= 4 && !ni; ++c)
                     if ((long)ntn * ((a.M + 32 * c - 1) / (32 * c)) <= 256) ni = c;
                 const long tiles = ni ? (long)ntn * ((a.M + 32 * ni - 1) / (32 * ni)) : 0;
+                // (EPI_RESID_LN: only where the plain residual epilogue would leave the small-tile kernel too, at >= 112 tiles of 128 rows.
+                //  Its epilogue is twice as long as the plain one and one wave per SIMD issues it; measured on ViT-L with the fold on:
+                //  batch 2 (88 such tiles) small-tile kernel - 1.5 % of the forward against the unfolded path, 172 tiles of 64 rows - 8 %,
+                //  116 of 96 rows - 13 %; batch 3 (132) small-tile - 16 %, 172 tiles of 96 rows - 3.5 %; batch 4 (172) small-tile - 15 %,
+                //  232 tiles of 96 rows - 2.5 %, 172 of 128 rows - 5.6 % -- profiles/r06_ln_fold.md)
+                if (epi == EPI_RESID_LN && (long)ntn * ((a.M + 127) / 128) < 112) ni = 0;
                 if (ni && tiles >= 112) return DINO_LEAF(launch_gemm4_short(dt, epi, a, ni, st), "gemm4_short<%d>", 32 * ni);
             }
         }
@@ -883,7 +889,12 @@ hipError_t launch_gemm(DType dt, Epilogue epi, const GemmArgs& a_in, hipStream_t
         const bool g4 = ln || (gen != 2 && gemm4_ok(epi, a) && (gen == 4 || (a.K >= 1024 && !(epi == EPI_RESID && a.K < 2048))));
         switch (plan) {
             case 'A': return g4 ? DINO_LEAF(launch_gemm4(dt, epi, a, st), "gemm4<256>") : DINO_LEAF(launch_gemm2(dt, epi, a, st), "gemm2<256>");
-            case 'B': return DINO_LEAF(launch_gemm2_192(dt, epi, a, st), "gemm2<192>");
+            case 'B': {
+                if (!ln) return DINO_LEAF(launch_gemm2_192(dt, epi, a, st), "gemm2<192>");
+                GemmArgs a0 = a;  // (the LN-fold epilogues: gemm4.hip's two-height launch with an empty 256-row part)
+                a0.M = 0;
+                return DINO_LEAF(launch_gemm4_mixed(dt, epi, a0, a, st), "gemm4_mixed<0+192>");
+            }
             case 'C':
                 return g4 ? DINO_LEAF(launch_gemm4_mixed(dt, epi, a1, a2, st), "gemm4_mixed<256+192>")
                           : DINO_LEAF(launch_gemm2_mixed(dt, epi, a1, a2, st), "gemm2_mixed<256+192>");

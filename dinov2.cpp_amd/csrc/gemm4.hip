@@ -914,7 +914,9 @@ hipError_t launch_gemm4_mixed(DType dt, Epilogue epi, const GemmArgs& a, const G
 
 // Short tiles (64 / 96 / 128 rows), one per workgroup: for launches whose 256-row tiles would leave most CUs idle (batch 1: M = 1 374 ->
 // QKV 15 panels of 96 rows x 12 column tiles = 180 workgroups instead of 132 of 128 rows; FFN-in 240 instead of 176).  The 2-byte
-// epilogues only (the f32 ones go to the small-tile kernel at these sizes).  Same K order, same bits.
+// epilogues (the plain f32 ones go to the small-tile kernel or to gemm2.hip's 128-row tiles at these sizes) and EPI_RESID_LN, which has no
+// gemm2.hip form (batch 4: without it the LN fold fell back to the small-tile kernel where the default path runs 128-row tiles: - 15 %).
+// Same K order, same bits.
 template <typename T, int NI>
 static hipError_t launch4_short_t(Epilogue epi, const GemmArgs& a, hipStream_t st) {
     const int tiles = (a.N / 256) * ((a.M + 32 * NI - 1) / (32 * NI));
@@ -927,6 +929,7 @@ static hipError_t launch4_short_t(Epilogue epi, const GemmArgs& a, hipStream_t s
         case EPI_QKV_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_QKV_LN, NI>), grid, block, G4_LDS, st, a); break;
         case EPI_GELU_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_GELU_LN, NI>), grid, block, G4_LDS, st, a); break;
         case EPI_SWIGLU_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_SWIGLU_LN, NI>), grid, block, G4_LDS, st, a); break;
+        case EPI_RESID_LN: hipLaunchKernelGGL((gemm4_kernel<T, EPI_RESID_LN, NI>), grid, block, G4_LDS, st, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -945,6 +948,7 @@ static hipError_t attr4_short_t() {
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_QKV_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_GELU_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_SWIGLU_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<T, EPI_RESID_LN, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G4_LDS);
     return e;
 }
 

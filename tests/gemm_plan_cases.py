@@ -219,34 +219,46 @@ LN_COVERAGE_CASES = [
     (1, 7, 1028, 2304, 768),  # gemm4_short<64>
     (0, 8, 5480, 1536, 384),  # gemm4<256>
     (1, 8, 5480, 1536, 384),  # gemm4<256>
+    (0, 6, 5480, 768, 768),  # gemm4_short<96>
+    (1, 6, 5480, 768, 768),  # gemm4_short<96>
     (0, 9, 257, 8192, 1536),  # gemm4_short<64>
     (1, 9, 257, 8192, 1536),  # gemm4_short<64>
     (0, 7, 8224, 1152, 384),  # small<128x128,w2x2,st2,ks1>
     (1, 7, 8224, 1152, 384),  # small<128x128,w2x2,st2,ks1>
     (0, 7, 2056, 2304, 768),  # gemm4_short<96>
     (1, 7, 2056, 2304, 768),  # gemm4_short<96>
-    (0, 7, 10960, 1152, 384),  # gemm4<256>;small<64x128,w2x4,st3,ks2>
-    (1, 7, 10960, 1152, 384),  # gemm4<256>;small<64x128,w2x4,st3,ks2>
+    (0, 7, 10960, 1152, 384),  # gemm4_mixed<0+192>;small<64x128,w2x4,st3,ks2>
+    (1, 7, 10960, 1152, 384),  # gemm4_mixed<0+192>;small<64x128,w2x4,st3,ks2>
     (0, 7, 2740, 2304, 768),  # gemm4_short<128>
     (1, 7, 2740, 2304, 768),  # gemm4_short<128>
     (0, 8, 2056, 3072, 768),  # gemm4_short<128>
     (1, 8, 2056, 3072, 768),  # gemm4_short<128>
-    (0, 6, 43840, 384, 384),  # gemm4<256>;small<64x128,w2x2,st2,ks1>
-    (1, 6, 43840, 384, 384),  # gemm4<256>;small<64x128,w2x2,st2,ks1>
+    (0, 6, 8224, 768, 768),  # gemm4_short<128>
+    (1, 6, 8224, 768, 768),  # gemm4_short<128>
+    (0, 6, 43840, 384, 384),  # gemm4_mixed<0+192>;small<64x128,w2x2,st2,ks1>
+    (1, 6, 43840, 384, 384),  # gemm4_mixed<0+192>;small<64x128,w2x2,st2,ks1>
+    (0, 6, 10960, 768, 768),  # gemm4<256>
+    (1, 6, 10960, 768, 768),  # gemm4<256>
     (0, 9, 514, 8192, 1536),  # gemm4_short<96>
     (1, 9, 514, 8192, 1536),  # gemm4_short<96>
+    (0, 7, 16448, 1152, 384),  # gemm4<256>;small<32x64,w1x4,st3,ks2>;small<64x128,w2x2,st3,ks1>
+    (1, 7, 16448, 1152, 384),  # gemm4<256>;small<32x64,w1x4,st3,ks2>;small<64x128,w2x2,st3,ks1>
     (0, 8, 16448, 1536, 384),  # gemm4_mixed<256+192>
     (1, 8, 16448, 1536, 384),  # gemm4_mixed<256+192>
-    (0, 6, 87680, 384, 384),  # gemm4_mixed<256+192>;small<128x128,w2x2,st2,ks1>
-    (1, 6, 87680, 384, 384),  # gemm4_mixed<256+192>;small<128x128,w2x2,st2,ks1>
-    (0, 9, 1028, 8192, 1536),  # gemm4<256>
-    (1, 9, 1028, 8192, 1536),  # gemm4<256>
+    (0, 8, 2740, 4096, 1024),  # gemm4_mixed<0+192>
+    (1, 8, 2740, 4096, 1024),  # gemm4_mixed<0+192>
+    (0, 6, 87680, 384, 384),  # gemm4_mixed<0+192>;small<128x128,w2x2,st2,ks1>
+    (1, 6, 87680, 384, 384),  # gemm4_mixed<0+192>;small<128x128,w2x2,st2,ks1>
+    (0, 9, 1028, 8192, 1536),  # gemm4_mixed<0+192>
+    (1, 9, 1028, 8192, 1536),  # gemm4_mixed<0+192>
     (0, 7, 43840, 1152, 384),  # gemm4_mixed<256+192>;small<64x128,w2x2,st2,ks1>
     (1, 7, 43840, 1152, 384),  # gemm4_mixed<256+192>;small<64x128,w2x2,st2,ks1>
     (0, 9, 2056, 8192, 1536),  # gemm4<256>;small<64x128,w4x2,st3,ks2>
     (1, 9, 2056, 8192, 1536),  # gemm4<256>;small<64x128,w4x2,st3,ks2>
-    (0, 9, 2740, 8192, 1536),  # gemm4_mixed<256+192>
-    (1, 9, 2740, 8192, 1536),  # gemm4_mixed<256+192>
+    (0, 6, 16448, 1536, 1536),  # gemm4_mixed<256+192>
+    (1, 6, 16448, 1536, 1536),  # gemm4_mixed<256+192>
+    (0, 9, 5480, 8192, 1536),  # gemm4_mixed<256+192>
+    (1, 9, 5480, 8192, 1536),  # gemm4_mixed<256+192>
     (0, 9, 16704, 8192, 1536),  # gemm4<256>;small<64x128,w2x2,st3,ks1>
     (1, 9, 16704, 8192, 1536),  # gemm4<256>;small<64x128,w2x2,st3,ks1>
 ]

@@ -108,7 +108,8 @@ def test_ln_fold_vectors(api, dt):
 
 # (M, N, K, substring the dispatcher's plan must contain): every plan a producer launch can take
 _PRODUCER_CASES = [(41100, 1024, 384, "gemm4_mixed<256+192>"), (98200, 512, 256, "gemm4<256>"), (16700, 1024, 256, "gemm4<256>;small<32x64"),
-                   (11500, 1536, 256, "gemm4<256>;small<64x128,w2x4"), (37500, 384, 256, "gemm4<256>;small<64x128,w2x2"),
+                   (11500, 1536, 256, "gemm4<256>;small<64x128,w2x4"), (37500, 384, 256, "gemm4_mixed<0+192>;small<64x128,w2x2"),
+                   (5496, 1024, 1024, "gemm4_short<96>"), (10992, 1024, 4096, "gemm4_mixed<0+192>"),
                    (1374, 1024, 256, "small<64x128,w2x4"), (300, 128, 128, "small<64x128,w4x2"), (261, 384, 384, "small<32x64"),
                    (20000, 384, 384, "small<64x128,w2x2,st2"), (5000, 512, 256, "small<64x128,w2x2,st3")]
 
