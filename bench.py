@@ -226,7 +226,7 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "front": "group",
                "front_note": "dinov2_hip_group_submit/_wait: one process, one host thread, two batches in flight, page-locked host buffers in "
                              "and out (PCIe-inclusive: NOT comparable with the device-resident `value` of the default front)",
-               "devices": g["devices"], "group_broadcast_ms": g["group_broadcast_ms"],
+               "devices": g["devices"], "group_broadcast_ms": g["group_broadcast_ms"], "topology": g["topology"],
                "config": {"workload": f"dinov2-{args.model} (ViT-{args.model[0].upper()}/14, {args.registers} registers) {args.wtype} GGUF, "
                                       f"{args.size}x{args.size}, batch={args.batch} per GPU, classify head, random-init weights",
                           "global_batch": g["global_batch"], "parallelism": f"dp{len(devices)}", "gflop_per_image": round(gflop_img, 1)},
@@ -464,6 +464,8 @@ def main():
                        "weight_broadcast_ms": round(g_bcast_ms, 2), "arena_mb": round(gbytes / 1e6, 1), "finite": g_fin == 0.0}
             del gs
             gm.close()
+        except Exception as e:  # a side leg: the headline was measured above and rank 0 still owes the driver its line
+            config4 = {"error": repr(e)}
         finally:
             # the ViT-L model again for the rank-0 measurements below, whatever happened in the leg
             if rank == 0 and model is None:
@@ -639,8 +641,24 @@ def main():
     if world > 1 and not args.no_host_buffers:
         try:
             devs = [0] * world if dryrun else list(range(world))
-            with wd.stage("group front over %d devices (rank 0, one process)" % world, 900.0):
-                group_leg = group_front(api, path, devs, dt, B, S, num_classes, steps=max(4, min(args.steps, 10)), windows=3)
+            # ... in a CHILD process (this file with --front group): the multi-device lanes of group.cpp have only ever time-shared one
+            # device, and a crash or a hang in them must cost this field, not the headline line rank 0 still owes the driver
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                     "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--front", "group", "--gpus", str(world), "--devices", ",".join(map(str, devs)),
+                   "--model", args.model, "--batch", str(B), "--size", str(S), "--registers", str(args.registers), "--dtype", args.dtype,
+                   "--wtype", args.wtype, "--steps", str(max(4, min(args.steps, 10))), "--windows", "3", "--warmup", "2"]
+            with wd.stage("group front over %d devices (child process)" % world, 700.0):
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            lines = [ln for ln in cp.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+            if cp.returncode != 0 or not lines:
+                raise RuntimeError("child exit code %d: %s" % (cp.returncode, cp.stderr.decode(errors="replace")[-400:]))
+            child = json.loads(lines[-1])
+            group_leg = {k: child.get(k) for k in ("value", "unit", "ms_per_step", "steps", "windows", "window_values", "devices",
+                                                   "group_broadcast_ms", "front_note", "whole_forward_tflops_per_gpu")}
+            group_leg["global_batch"] = child["config"]["global_batch"]
+            group_leg["topology"] = child.get("topology")
             group_leg["ratio_to_value"] = round(group_leg["value"] / value, 4)
         except BaseException as e:
             group_leg = {"error": repr(e)}
