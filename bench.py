@@ -649,8 +649,9 @@ def main():
             cmd = [sys.executable, os.path.abspath(__file__), "--front", "group", "--gpus", str(world), "--devices", ",".join(map(str, devs)),
                    "--model", args.model, "--batch", str(B), "--size", str(S), "--registers", str(args.registers), "--dtype", args.dtype,
                    "--wtype", args.wtype, "--steps", str(max(4, min(args.steps, 10))), "--windows", "3", "--warmup", "2"]
-            with wd.stage("group front over %d devices (child process)" % world, 700.0):
-                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            with wd.stage("group front over %d devices (child process)" % world, 330.0):
+                # (a healthy run takes under a minute; the limit bounds what a hang in the never-exercised multi-device path can add to the job)
+                cp = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=270)
             lines = [ln for ln in cp.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
             if cp.returncode != 0 or not lines:
                 raise RuntimeError("child exit code %d: %s" % (cp.returncode, cp.stderr.decode(errors="replace")[-400:]))
