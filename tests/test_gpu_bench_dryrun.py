@@ -54,6 +54,11 @@ def test_bench_multi_rank_dry_run(n, batch):
     assert all(r["images_per_sec_min"] <= r["images_per_sec"] <= r["images_per_sec_max"] for r in pr)
     assert max(r["ms_per_step"] for r in pr) <= j["ms_per_step"] * 1.5  # `value` is the max over ranks per window: no rank far beyond it
     assert j["value_host_buffers"] is None  # (N = 1 only)
+    # N > 1: rank 0 also times the one-process group front over all N devices -- in a child process, so that a crash there costs this field only
+    gf = j["group_front"]
+    assert gf and "error" not in gf, gf
+    assert gf["value"] > 0 and gf["global_batch"] == n * batch and len(gf["devices"]) == n and len(gf["topology"]) == n
+    assert 0.3 < gf["ratio_to_value"] < 1.3
 
 
 def test_bench_group_front_eight_entries():
