@@ -167,6 +167,7 @@ def lib():
     L.dinov2_hip_op_gemm_resid_ln.argtypes = [i32, fp, fp, fp, fp, fp, fp, fp, fp, i32, i32, i32]
     L.dinov2_hip_op_gemm_ln_consumer.argtypes = [i32, i32, fp, fp, fp, fp, fp, C.c_float, fp, i32, i32, i32, i32, i32, C.c_float]
     L.dinov2_hip_op_ln_prepare.argtypes = [i32, fp, fp, fp, fp, i32, i32]
+    L.dinov2_hip_op_im2col.argtypes = [i32, fp, fp, i32, i32, i32, i32, i32, i32]
     L.dinov2_hip_op_ln_fold_vectors.argtypes = [i32, fp, fp, fp, fp, fp, fp, i32, i32]
     L.dinov2_hip_op_attention.argtypes = [i32, fp, fp, i32, i32, i32, i32]
     L.dinov2_hip_op_layernorm.argtypes = [i32, fp, fp, fp, fp, i32, i32, C.c_float]

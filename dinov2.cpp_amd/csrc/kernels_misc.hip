@@ -213,47 +213,81 @@ hipError_t launch_ln_fold_vectors(DType dt, const void* W, const float* bias, co
 // patch vector order (c, ky, kx) with kx fastest == flattening the [H,3,14,14] weight row; c is the RGB index
 // (dino_predict repacks BGR-interleaved to RGB-planar first, dinov2.cpp:914-931 -- folded into the gather here).
 // ---------------------------------------------------------------------------------------------------------
+// One workgroup per (image, patch row, chunk of <= IM2COL_CHUNK patches): the 3 x ps image rows of the chunk are read as contiguous runs
+// (coalesced; the first version gathered 8 pixels per thread from 8 addresses and ran at 1.7 TB/s), converted, laid out as the chunk's
+// [patches][Kpad] block in LDS, and leave as whole 16-byte pieces of whole rows.  Same values as ever: one (T) rounding of the f32 pixel.
+constexpr int IM2COL_CHUNK = 10;
 template <typename T>
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int Hh,
-                                                     int Ww, int ps, int Kpad, int layout) {
+__global__ __launch_bounds__(1024) void im2col_kernel(const float* __restrict__ img, T* __restrict__ col, int B, int Hh,
+                                                     int Ww, int ps, int Kpad, int layout, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char im2col_lds[];
+    T* const tile = (T*)im2col_lds;  // [np][Kpad]
     const int w0 = Ww / ps, h0 = Hh / ps, P = w0 * h0;
-    const int cpr = Kpad >> 3;  // 8-element chunks per row
-    const size_t total = (size_t)B * P * cpr;
-    const int Kreal = 3 * ps * ps, pp2 = ps * ps;
-    typedef T t8 __attribute__((ext_vector_type(8)));
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % cpr);
-        const size_t rowi = idx / cpr;
-        const int p = (int)(rowi % P), b = (int)(rowi / P);
-        const int py = p / w0, px = p - py * w0;
-        t8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int k = ch * 8 + e;
-            float v = 0.f;
-            if (k < Kreal) {
-                const int c = k / pp2, rem = k - c * pp2;
-                const int ky = rem / ps, kx = rem - ky * ps;
-                const int yy = py * ps + ky, xx = px * ps + kx;
-                v = layout == 1 ? img[(((size_t)b * 3 + c) * Hh + yy) * Ww + xx]
-                                : img[(((size_t)b * Hh + yy) * Ww + xx) * 3 + (2 - c)];
-            }
-            o[e] = (T)v;
-        }
-        *(t8*)(col + rowi * Kpad + ch * 8) = o;
+    const int ck = blockIdx.x % nchunk, py = (blockIdx.x / nchunk) % h0, b = blockIdx.x / (nchunk * h0);
+    const int px0 = ck * IM2COL_CHUNK, np = min(IM2COL_CHUNK, w0 - px0);
+    const int pp2 = ps * ps, Kreal = 3 * pp2, run = np * ps;
+    const int tid = threadIdx.x, nth = blockDim.x;  // 4 or 16 waves (launch_im2col)
+    for (int i = tid; i < np * (Kpad - Kreal); i += nth) {  // the K padding of every row
+        const int r = i / (Kpad - Kreal), k = Kreal + i - r * (Kpad - Kreal);
+        tile[r * Kpad + k] = (T)0.f;
     }
+    // One contiguous run of the chunk per wave and step -- planar: 3 * ps runs of np * ps floats (channel c, row ky); interleaved: ps runs of
+    // 3 * np * ps -- so that everything that needs a division is wave-uniform; per element only x / ps and e / 3, by multiplication
+    // (magic = 65536 / ps + 1: exact for x < 65536 / ps, the launcher checks).  Five independent loads per lane before the first LDS store
+    // (a plain strided loop is one dependent global round trip per element).
+    const unsigned magic = 65536u / (unsigned)ps + 1u;
+    const int nrun = layout == 1 ? 3 * ps : ps, rlen = layout == 1 ? run : 3 * run;
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int U = 5;
+    for (int rr = wv; rr < nrun; rr += (nth >> 6)) {
+        const int c0 = layout == 1 ? rr / ps : 0, ky = layout == 1 ? rr - c0 * ps : rr;
+        const float* src = layout == 1 ? img + (((size_t)b * 3 + c0) * Hh + (size_t)py * ps + ky) * Ww + (size_t)px0 * ps
+                                       : img + (((size_t)b * Hh + (size_t)py * ps + ky) * Ww + (size_t)px0 * ps) * 3;
+        T* const trow = tile + c0 * pp2 + ky * ps;
+        for (int e0 = lane; e0 < rlen; e0 += 64 * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e0 + 64 * u < rlen) v[u] = src[e0 + 64 * u];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + 64 * u;
+                if (e < rlen) {
+                    int xo = e, cc = 0;
+                    if (layout != 1) {
+                        xo = (int)(((unsigned)e * 21846u) >> 16);  // e / 3 (exact below 32 768)
+                        cc = (2 - (e - 3 * xo)) * pp2;             // position 0 / 1 / 2 = B / G / R -> RGB index 2 / 1 / 0
+                    }
+                    const int pl = (int)(((unsigned)xo * magic) >> 16), kx = xo - pl * ps;
+                    trow[pl * Kpad + cc + kx] = (T)v[u];
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int cpr = Kpad >> 3;  // 16-byte pieces per row
+    T* const dst = col + ((size_t)b * P + (size_t)py * w0 + px0) * Kpad;  // the chunk's rows are consecutive in col
+    for (int i = tid; i < np * cpr; i += nth) ((uint4*)dst)[i] = ((const uint4*)tile)[i];
 }
 
 hipError_t launch_im2col(DType dt, const float* img, void* col, int B, int Hh, int Ww, int patch, int Kpad, int layout,
                          hipStream_t st) {
-    const size_t total = (size_t)B * (Hh / patch) * (Ww / patch) * (Kpad / 8);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (patch <= 0 || Kpad % 8 != 0 || Kpad < 3 * patch * patch) return hipErrorInvalidValue;
+    const int w0 = Ww / patch, h0 = Hh / patch;
+    if (w0 <= 0 || h0 <= 0 || B <= 0) return hipErrorInvalidValue;
+    const int nchunk = (w0 + IM2COL_CHUNK - 1) / IM2COL_CHUNK;
+    const size_t lds = (size_t)IM2COL_CHUNK * Kpad * 2;
+    if (lds > 64 * 1024 || 3 * IM2COL_CHUNK * patch >= 32768) return hipErrorInvalidValue;  // (Kpad <= 1 638: patch sizes up to 23)
+    for (unsigned x = 0, mg = 65536u / (unsigned)patch + 1u; x < (unsigned)(IM2COL_CHUNK * patch); ++x)
+        if (((x * mg) >> 16) != x / (unsigned)patch) return hipErrorInvalidValue;  // (never for patch <= 23; the kernel divides by multiplication)
+    // few workgroups (batch 1: 148): 16 waves each, so that a wave's chain of runs is three deep (10 us; 15 with four waves); many (batch 32:
+    // 4 736): four waves, more workgroups per CU overlap better (51 us against 69; the gather this replaces took 92 / 10 us)
+    const size_t nwg = (size_t)B * h0 * nchunk;
+    const dim3 grid((unsigned)nwg), block(nwg >= 1024 ? 256 : 1024);
     if (dt == DT_F16)
-        hipLaunchKernelGGL(im2col_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, img, (_Float16*)col, B, Hh, Ww, patch,
-                           Kpad, layout);
+        hipLaunchKernelGGL(im2col_kernel<_Float16>, grid, block, lds, st, img, (_Float16*)col, B, Hh, Ww, patch, Kpad, layout, nchunk);
     else
-        hipLaunchKernelGGL(im2col_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, img, (__bf16*)col, B, Hh, Ww, patch, Kpad,
-                           layout);
+        hipLaunchKernelGGL(im2col_kernel<__bf16>, grid, block, lds, st, img, (__bf16*)col, B, Hh, Ww, patch, Kpad, layout, nchunk);
     return hipGetLastError();
 }
 

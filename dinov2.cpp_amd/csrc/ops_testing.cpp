@@ -177,6 +177,22 @@ extern "C" int dinov2_hip_op_ln_prepare(int32_t dtype, const float* x, const flo
     return 0;
 }
 
+extern "C" int dinov2_hip_op_im2col(int32_t dtype, const float* img, float* col, int32_t B, int32_t Hh, int32_t Ww, int32_t patch, int32_t Kpad,
+                                    int32_t layout) {
+    const DType dt = dtype == 1 ? DT_BF16 : DT_F16;
+    if (B <= 0 || Hh <= 0 || Ww <= 0 || patch <= 0) return -1;
+    const size_t npix = (size_t)B * 3 * Hh * Ww, rows = (size_t)B * (Hh / patch) * (Ww / patch);
+    DevBuf dI, dC;
+    OP_TRY(dI.alloc(sizeof(float) * npix));
+    OP_TRY(hipMemcpy(dI.p, img, sizeof(float) * npix, hipMemcpyHostToDevice));
+    OP_TRY(dC.alloc(2 * rows * (size_t)Kpad));
+    OP_TRY(hipMemset(dC.p, 0xff, 2 * rows * (size_t)Kpad));  // (a NaN pattern: every element must be written)
+    OP_TRY(launch_im2col(dt, (const float*)dI.p, dC.p, B, Hh, Ww, patch, Kpad, layout, nullptr));
+    OP_TRY(hipDeviceSynchronize());
+    OP_TRY(download_as(dt, dC.p, rows * (size_t)Kpad, col));
+    return 0;
+}
+
 extern "C" int dinov2_hip_op_ln_fold_vectors(int32_t dtype, const float* W, const float* bias, const float* gamma, const float* beta, float* s_out,
                                              float* c_out, int32_t N, int32_t K) {
     const DType dt = dtype == 1 ? DT_BF16 : DT_F16;

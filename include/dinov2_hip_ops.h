@@ -32,6 +32,9 @@ int dinov2_hip_op_gemm_resid_ln(int32_t dtype, const float *A, const float *W, c
 int dinov2_hip_op_gemm_ln_consumer(int32_t dtype, int32_t epilogue, const float *A, const float *W, const float *ln_s, const float *ln_c,
                                    const float *stats, float eps, float *out, int32_t ldo, int32_t M, int32_t N, int32_t K, int32_t qcols,
                                    float qscale);
+/* im2col of the patch embedding (ggml_conv_2d_sk_p0, /root/reference/dinov2.cpp:636): img f32, layout 1 = RGB planar [B,3,H,W], 0 = BGR interleaved
+ * [B,H,W,3]; col [B * (H/patch) * (W/patch), Kpad] as f32 values of the compute type, k = c * patch^2 + ky * patch + kx, zero beyond 3 * patch^2 */
+int dinov2_hip_op_im2col(int32_t dtype, const float *img, float *col, int32_t B, int32_t Hh, int32_t Ww, int32_t patch, int32_t Kpad, int32_t layout);
 int dinov2_hip_op_ln_prepare(int32_t dtype, const float *x, const float *gamma, float *xg, float *stats, int32_t rows, int32_t H);
 int dinov2_hip_op_ln_fold_vectors(int32_t dtype, const float *W, const float *bias, const float *gamma, const float *beta, float *s_out,
                                   float *c_out, int32_t N, int32_t K);

@@ -749,3 +749,23 @@ def test_gemm_plan_coverage_case_bits(api, case):
         assert np.array_equal(small, out[:100]), (plan, "rows 0..99")
         last = M - 100 - M % 100
         assert np.array_equal(small, out[last:last + 100]), (plan, "last whole copy of the rows")
+
+
+@pytest.mark.parametrize("dt", [F16, BF16])
+@pytest.mark.parametrize("layout", [1, 0])
+@pytest.mark.parametrize("B,Hh,Ww,ps", [(2, 518, 518, 14), (1, 224, 224, 14), (3, 70, 98, 14), (1, 490, 868, 14), (2, 64, 83, 16), (1, 14, 14, 14)])
+def test_im2col_bit_exact(api, dt, layout, B, Hh, Ww, ps):
+    """im2col of ggml_conv_2d_sk_p0 (/root/reference/dinov2.cpp:636; BGR-interleaved input: the repack of :914-931 folded in): every element
+    of [B * P, Kpad] equals the compute-type rounding of its pixel, k = c * ps^2 + ky * ps + kx with c the RGB index, zero in the K padding --
+    square, non-square, several chunks per patch row (868 wide: 62 patches), widths that are no multiple of the patch size, one patch."""
+    rng = np.random.default_rng(B * 1000 + Ww)
+    Kpad = (3 * ps * ps + 63) // 64 * 64
+    rgb = (rng.standard_normal((B, 3, Hh, Ww)) * 1.5).astype(np.float32)
+    img = rgb if layout == 1 else np.ascontiguousarray(rgb[:, ::-1].transpose(0, 2, 3, 1))  # BGR interleaved
+    h0, w0 = Hh // ps, Ww // ps
+    col = np.full((B * h0 * w0, Kpad), np.nan, np.float32)
+    assert api.lib().dinov2_hip_op_im2col(dt, _p(img), _p(col), B, Hh, Ww, ps, Kpad, layout) == 0
+    ref = np.zeros((B, h0, w0, Kpad), np.float32)
+    patches = rgb[:, :, :h0 * ps, :w0 * ps].reshape(B, 3, h0, ps, w0, ps).transpose(0, 2, 4, 1, 3, 5).reshape(B, h0, w0, 3 * ps * ps)
+    ref[..., :3 * ps * ps] = _round(patches, dt)
+    assert np.array_equal(col, ref.reshape(B * h0 * w0, Kpad))
