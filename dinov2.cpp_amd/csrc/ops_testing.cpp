@@ -299,21 +299,26 @@ extern "C" float dinov2_hip_op_gemm_bench(int32_t dtype, int32_t epilogue, int32
     // extra elements per row of A / W (row strides K + pad instead of the dense K): 0 in normal use; profiles/r02_gemm_kloop.md
     // measured 64 (= 128 bytes) as neutral, i.e. no power-of-two-stride channel conflict to pad away
     const int padA = 0, padW = 0;
+    // EPI_PATCH writes token rows (image b, patch p) -> row b * T + 1 + R + p and reads the position embedding [1 + P, N]: shaped like the model
+    // (P = 1369 patches, 4 registers) when M is a multiple of 1369, one "image" of M patches otherwise
+    const int pP = epilogue == EPI_PATCH ? (M % 1369 == 0 ? 1369 : M) : 1, pR = epilogue == EPI_PATCH && M % 1369 == 0 ? 4 : 0;
+    const int pT = pP + 1 + pR;
+    const size_t out_elems = epilogue == EPI_PATCH ? (size_t)(M / pP) * pT * N : (size_t)M * N;
+    const size_t aux_elems = epilogue == EPI_PATCH ? (size_t)(pP + 1) * N : (size_t)std::max(N, 4096) * 2;
     if (dA.alloc((size_t)M * (K + padA) * 2) != hipSuccess || dW.alloc((size_t)N * (K + padW) * 2) != hipSuccess ||
-        dB.alloc((size_t)N * 4) != hipSuccess || dX.alloc((size_t)std::max(N, 4096) * 4 * 2) != hipSuccess ||
-        dO.alloc((size_t)M * N * 4) != hipSuccess)
+        dB.alloc((size_t)N * 4) != hipSuccess || dX.alloc(aux_elems * 4) != hipSuccess || dO.alloc(out_elems * 4) != hipSuccess)
         return -1.f;
     fill_random_t(dt, dA.p, (size_t)M * (K + padA), 1, 1.0f);
     fill_random_t(dt, dW.p, (size_t)N * (K + padW), 2, 0.05f);
     (void)hipMemset(dB.p, 0, (size_t)N * 4);
-    (void)hipMemset(dX.p, 0, (size_t)std::max(N, 4096) * 8);
-    (void)hipMemset(dO.p, 0, (size_t)M * N * 4);
+    (void)hipMemset(dX.p, 0, aux_elems * 4);
+    (void)hipMemset(dO.p, 0, out_elems * 4);
     GemmArgs a{};
     a.A = dA.p; a.W = dW.p; a.bias = (const float*)dB.p; a.out = dO.p; a.aux = (const float*)dX.p;
     a.M = M; a.N = N; a.K = K; a.ldo = epilogue == EPI_SWIGLU ? N / 2 : N; a.P = 1; a.T = 2; a.R = 0;
     a.lda = K + padA; a.ldw = K + padW;
     a.qcols = N / 3; a.qscale = 0.125f;
-    if (epilogue == EPI_PATCH) { a.P = M; a.T = M + 1; }
+    if (epilogue == EPI_PATCH) { a.P = pP; a.T = pT; a.R = pR; }
     DevBuf dSt, dXg, dV;
     if (epilogue >= EPI_RESID_LN) {  // LN fold: statistics of unit-variance rows, gamma = 1, s = 0, c = 0
         const int hc = epilogue == EPI_RESID_LN ? N : K;
