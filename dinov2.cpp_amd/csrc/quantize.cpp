@@ -227,6 +227,9 @@ extern "C" int dinov2_hip_quantize(const char* fname_inp, const char* fname_out,
                 for (int j = 0; j < QK; ++j) {
                     if (t.type == 0) std::memcpy(&x[j], src + (b * QK + j) * 4, 4);
                     else { uint16_t h; std::memcpy(&h, src + (b * QK + j) * 2, 2); x[j] = f16_to_f32(h); }
+                    // (a NaN / Inf weight has no block encoding -- the float -> int casts below would be undefined behaviour -- and means a damaged
+                    //  file: refuse, as ggml's quantiser validates its rows, rather than write something that loads)
+                    if (!std::isfinite(x[j])) { fail(err, errlen, "non-finite value in tensor ", t.name); return DINOV2_HIP_ERR_FORMAT; }
                 }
                 quant_block(x, itype, &o[(size_t)b * block_bytes(itype)]);
             }

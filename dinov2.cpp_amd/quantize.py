@@ -99,6 +99,8 @@ def dino_model_quantize(fname_inp: str, fname_out: str, itype: int) -> bool:
                 a = np.frombuffer(raw, np.float16).astype(np.float32)
             else:
                 raise ValueError(f"unsupported tensor type {gtype} for '{name}'")  # dinov2.cpp:425
+            if not np.isfinite(a).all():  # (same rule as csrc/quantize.cpp: a NaN / Inf weight has no block encoding)
+                raise ValueError(f"non-finite value in tensor '{name}'")
             q = gw.quantize(a.reshape(-1, ne[0]), itype).tobytes()
             w.add_raw_tensor(name, shape, itype, q)
             total_out += len(q)

@@ -449,3 +449,48 @@ def test_quantize_keeps_a_non_default_alignment(api, pkg, golden_dir, tmp_path, 
             assert np.array_equal(ta.raw, gw.quantize(ts.to_f32(), itype).reshape(-1)), name
         else:
             assert np.array_equal(ta.to_f32(), ts.to_f32()), name
+
+
+def test_gguf_reader_and_quantiser_survive_mutants_under_sanitizers(golden_dir, tmp_path):
+    """tests/cpp/gguf_fuzz.cpp: the host-side GGUF code (csrc/gguf_reader.cpp, csrc/quantize.cpp) built with AddressSanitizer + UndefinedBehaviorSanitizer,
+    fed 3 000 mutants per fixture (byte flips, 4- / 8-byte fields overwritten with extreme values, truncations); every mutant is opened, every
+    tensor's first and last data byte is touched the way the loader does, every eighth mutant goes through the quantiser.  A file may be refused --
+    with a message -- never read out of bounds.  (Round 6 found one thing that way: NaN weights reached the quantiser's float -> int casts; both
+    quantisers now refuse non-finite weights, as ggml's row validation does.)  The sanitizer runtimes come with ROCm's clang; skipped without them."""
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("ROCm clang not available")
+    src = os.path.join(ROOT, "dinov2.cpp_amd", "csrc")
+    exe = str(tmp_path / "gguf_fuzz")
+    r = subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        os.path.join(ROOT, "tests", "cpp", "gguf_fuzz.cpp"), os.path.join(src, "gguf_reader.cpp"), os.path.join(src, "quantize.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    for seed, name in enumerate(("tiny_gelu_reg4.gguf", "tiny_swiglu_reg4.gguf")):
+        r = subprocess.run([exe, os.path.join(golden_dir, name), str(seed + 1), "3000", str(tmp_path)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        last = r.stdout.strip().splitlines()[-1]
+        assert last.startswith("mutants 3000") and "refused" in last, last
+        opened, refused = int(last.split("opened ")[1].split(",")[0]), int(last.split("refused ")[1].split(",")[0])
+        assert opened > 500 and refused > 500, last  # both outcomes were exercised
+
+
+def test_quantisers_refuse_non_finite_weights(api, pkg, golden_dir, tmp_path):
+    """A NaN / Inf weight has no block encoding (and means a damaged file): the native quantiser and the Python tool both refuse it, with the tensor's name."""
+    pyq = import_module(PKG_NAME + ".quantize")
+    path = os.path.join(golden_dir, "tiny_gelu_reg4.gguf")
+    good = bytearray(open(path, "rb").read())
+    t = G.GGUFFile(path).tensors["encoder.layer.0.mlp.fc1.weight"]
+    assert t.gtype in (G.GGML_F16, G.GGML_F32)
+    pos = bytes(good).find(t.raw.tobytes()[:64])
+    assert pos > 0
+    nan = struct.pack("<H", 0x7E00) if t.gtype == G.GGML_F16 else struct.pack("<f", float("nan"))
+    good[pos:pos + len(nan)] = nan
+    bad = tmp_path / "nan.gguf"
+    bad.write_bytes(bytes(good))
+    err = C.create_string_buffer(256)
+    assert api.lib().dinov2_hip_quantize(str(bad).encode(), str(tmp_path / "out.gguf").encode(), 8, err, 256) == 2
+    assert b"non-finite" in err.value and b"fc1.weight" in err.value
+    with pytest.raises(ValueError, match="non-finite"):
+        pyq.dino_model_quantize(str(bad), str(tmp_path / "out2.gguf"), 8)
