@@ -64,3 +64,23 @@ def test_bicubic_equals_torch(api):
 
 # The -m gpu checks of the DEVICE preprocessing kernel (kernel output and kernel -> forward, both against the oracle) live in
 # tests/test_gpu_configs.py: test_preprocess_kernel_vs_oracle, test_device_preprocess_then_forward_vs_oracle.
+
+
+def test_host_preprocess_under_sanitizers(tmp_path):
+    """tests/cpp/preprocess_san.cpp: csrc/preprocess.cpp built with AddressSanitizer + UndefinedBehaviorSanitizer, both modes, 52 image sizes (1 x 1,
+    smaller than a patch, odd, 3 x 2000, random) x two patch sizes, the output buffer sized exactly as dinov2_hip_preprocess_size promises."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        pytest.skip("ROCm clang not available")
+    exe = str(tmp_path / "pp_san")
+    r = subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                        os.path.join(root, "tests", "cpp", "preprocess_san.cpp"), os.path.join(root, "dinov2.cpp_amd", "csrc", "preprocess.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        pytest.skip("sanitizer runtime not available: " + r.stderr[-200:])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.startswith("preprocessed 2"), r.stdout
